@@ -1,0 +1,118 @@
+/*
+ * nm.h — C-ABI of the MI355X-native NPT-HMC + replica-exchange engine (libnm_hip.so).
+ *
+ * This is the drop-in boundary for the data-parallel hot path of walkernr/neuralMelting's
+ * scripts/lammps_remcmc.py ("remcmc").  The reference has no FFI of its own for this path; the
+ * seam it offers is the set of per-replica Python functions its orchestration maps over
+ * (seam S-up).  Each entry point below replaces one of them, batched over all
+ * replicas ("slots", k = i*NT + j, i = pressure index, j = temperature index, remcmc:117) held by
+ * one GPU:
+ *
+ *   nm_create / nm_set_state   <- init_constants (remcmc:114-141) + the STATE lists (remcmc:432-433)
+ *   nm_run_block               <- gen_samples -> gen_sample -> move_mc   (remcmc:643-719)
+ *                                 incl. every LAMMPS call it makes        (remcmc:459-470, 477-640)
+ *   nm_get_thermo / nm_get_state <- lammps_extract + the returned state   (remcmc:377-391, 681-691)
+ *   nm_adapt                   <- gen_mc_params -> gen_mc_param           (remcmc:726-770)
+ *   nm_exchange                <- replica_exchange                        (remcmc:776-803)
+ *
+ * Conventions: extern "C"; plain pointers and sizes; int status (0 = ok, <0 = error, text via
+ * nm_last_error); no exceptions cross the boundary; the caller owns every host buffer, the
+ * context owns all device memory, its stream and events; one context per GPU; calls on one
+ * context are not re-entrant.  All arrays are C-contiguous; x and v are float64, xyz interleaved
+ * in atom-ID order exactly as LAMMPS gather_atoms('x',1,3) returns them (remcmc:381-382), so a
+ * .traj frame (remcmc:248-256) is a straight dump.
+ */
+#ifndef NM_H
+#define NM_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NM_OK 0
+#define NM_ERR_ARG (-1)       /* bad argument / configuration                              */
+#define NM_ERR_HIP (-2)       /* HIP runtime error (no device, allocation, launch)        */
+#define NM_ERR_STATE (-3)     /* a replica left the supported regime (see nm_last_error)  */
+#define NM_ERR_UNSUPPORTED (-4)
+
+#define NM_EL_LJ 0            /* units lj, fcc, lattice 1.122, mass 1     (remcmc:873-889) */
+#define NM_EL_AL 1            /* units metal, fcc, 4.046 A, mass 29.982  (remcmc:880,886) */
+
+#define NM_THERMO_COLS 17     /* temp pe ke virial vol dx dv dt ntp nap ntv nav nth nah ap av ah (remcmc:208) */
+#define NM_TRACE_COLS 4       /* branch (0 bulk PMC, 1 VMC, 2 HMC, 3 iter PMC), accepted, criterion, U after */
+#define NM_STATS_COLS 4       /* evaluations, list rebuilds, energy evaluations, sum of interacting pairs over those */
+
+typedef struct nm_ctx nm_ctx;
+
+typedef struct nm_config {
+    int32_t size;        /* sizeof(nm_config): ABI check                                        */
+    int32_t element;     /* NM_EL_*  (-e, remcmc:58)                                            */
+    int32_t natoms;      /* N = 4*SZ^3 for fcc (-ss, remcmc:60, 341-343)                        */
+    int32_t np, nt;      /* global P x T grid (-pn, -tn)                                        */
+    int32_t row0, nrows; /* pressure rows [row0,row0+nrows) owned by this context (sharding)   */
+    int32_t nstps;       /* NSTPS (-ts)                                                         */
+    int32_t bulk;        /* BM (-bm): 1 = bulk_position_mc, 0 = iter_position_mc                */
+    int32_t iter_revert; /* 0 = reference behaviour of iter PMC, 1 = corrected      */
+    int32_t device;      /* HIP device ordinal                                                  */
+    uint32_t seed;       /* SEED (256 in the reference, remcmc:851)                             */
+    double ppos, pvol;   /* PPOS, PVOL (-pm, -vm)                                               */
+    const float *P;      /* [np] float32 pressure grid   (remcmc:895)                           */
+    const float *T;      /* [nt] float32 temperature grid (remcmc:897)                          */
+} nm_config;
+
+/* life cycle */
+int nm_create(const nm_config *cfg, nm_ctx **out);
+int nm_destroy(nm_ctx *ctx);
+const char *nm_last_error(const nm_ctx *ctx);  /* ctx may be NULL: error of the last failed nm_create */
+int nm_nslots(const nm_ctx *ctx);              /* nrows*nt replicas held by this context               */
+int nm_natoms(const nm_ctx *ctx);
+
+/* thermodynamic constants per local slot: et = k_B T, pf = P/(k_B T) (init_constant, remcmc:114-132) */
+int nm_get_const(const nm_ctx *ctx, double *et, double *pf);
+
+/* replica state, local slots [k0,k0+nk): x[nk][3N], v[nk][3N], box[nk], dxdvdt[nk][3].  Any pointer may be NULL. */
+int nm_set_state(nm_ctx *ctx, int k0, int nk, const double *x, const double *v, const double *box,
+                 const double *dxdvdt);
+int nm_get_state(nm_ctx *ctx, int k0, int nk, double *x, double *v, double *box, double *dxdvdt);
+
+/* cycle index STEP of the main loop (remcmc:977); selects the RNG counter block. nm_run_block does not advance it. */
+int nm_set_step(nm_ctx *ctx, uint32_t step);
+
+/* gen_samples: MOD moves for every local replica, asynchronous on the context's stream */
+int nm_run_block(nm_ctx *ctx, int mod);
+/* rows[nslots][17] in the column order of remcmc:208 (values of the last nm_run_block; call before nm_adapt) */
+int nm_get_thermo(nm_ctx *ctx, double *rows);
+/* gen_mc_params: adapt dx, dv, dt, zero counters and ratios */
+int nm_adapt(nm_ctx *ctx);
+/* replica_exchange over the local pressure rows.  nswaps may be NULL (stays asynchronous). */
+int nm_exchange(nm_ctx *ctx, int *nswaps);
+/* waits for everything enqueued on the context; reports replicas that left the supported regime */
+int nm_synchronize(nm_ctx *ctx);
+
+/* measurement: HIP-event time of the nm_run_block kernel launches since the last reset */
+int nm_timing_reset(nm_ctx *ctx);
+int nm_timing_get(nm_ctx *ctx, int *launches, double *total_ms);
+/* per-slot work counters accumulated since the last reset: stats[nslots][NM_STATS_COLS] */
+int nm_stats_get(nm_ctx *ctx, double *stats, int reset);
+
+/* ---- test-only entry points ------------------------------------------------------------------ */
+/* batched lj_energy_force on the current states: U[nslots], W[nslots] (virial sum r.f), f[nslots][3N] (may be NULL) */
+int nm_eval(nm_ctx *ctx, double *U, double *W, double *f);
+/* externally supplied uniforms replacing the scalar draws of nm_run_block, consumed in the order of the
+   reference's np.random calls (remcmc:482,490,523,535,565,581,603,626,645); offsets[nslots+1]; NULL clears */
+int nm_set_rng_tape(nm_ctx *ctx, const double *tape, const int *offsets);
+/* one uniform per pair of the exchange sweep in sweep order (remcmc:795); NULL clears */
+int nm_set_exchange_tape(nm_ctx *ctx, const double *tape, int n);
+/* per-move records of the next nm_run_block calls: trace[nslots][mod][NM_TRACE_COLS] */
+int nm_set_trace(nm_ctx *ctx, int enable);
+int nm_get_trace(nm_ctx *ctx, double *trace, int mod);
+/* slot -> buffer map after exchanges (which initial configuration sits in slot k) */
+int nm_get_perm(nm_ctx *ctx, int *perm);
+/* dh of every pair visited by the last nm_exchange, sweep order */
+int nm_get_exchange_crit(nm_ctx *ctx, double *crit, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,515 @@
+// nm_api.hip — C-ABI (include/nm.h) over the gfx950 kernels.  The context owns all device memory, one HIP
+// stream and the HIP events used for measurement; nothing here falls back to a CPU path: without a usable
+// HIP device nm_create fails with NM_ERR_HIP.
+#include "../../include/nm.h"
+#include "nm_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace nm;
+
+namespace {
+
+typedef Cfg<1024, 4, unsigned char, true, true> CfgSmall;    // N <= 256: everything incl. the byte list in LDS
+typedef Cfg<1024, 1, unsigned short, false, true> CfgMid;    // N <= 864: list in HBM/L2, saved copies in LDS
+typedef Cfg<1024, 1, unsigned short, false, false> CfgLarge; // N <= 2048: saved copies spill to HBM as well
+
+thread_local std::string g_create_error;
+
+struct EvPair { hipEvent_t a, b; bool used; };
+
+} // namespace
+
+struct nm_ctx {
+    nm_config cfg;
+    int N, nslots, slot0, kind; // kind: 0 small, 1 mid, 2 large
+    int maxnb;
+    size_t lds_bytes, aux_doubles;
+    double lat, mass, kB, mvv2e, ftm2v, nktv2p;
+    uint32_t step;
+    hipStream_t stream;
+    // device
+    double *d_x, *d_v, *d_box, *d_steps, *d_therm, *d_count, *d_et, *d_pf, *d_tq, *d_stats;
+    float *d_ratio;
+    int *d_slot2buf, *d_status, *d_nswaps;
+    double *d_tape, *d_xtape, *d_trace, *d_xcrit, *d_evalU, *d_evalW, *d_evalF, *d_aux;
+    int *d_tape_off;
+    void *d_nbr;
+    size_t trace_cap;
+    int trace_on, trace_mod;
+    int xtape_n;
+    std::vector<double> h_et, h_pf, h_tq;
+    std::vector<EvPair> ev;
+    int ev_next;
+    int launches;
+    double total_ms;
+    std::string err;
+};
+
+namespace {
+
+int fail(nm_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail((c), NM_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+template <class T>
+hipError_t dalloc(T **p, size_t n) { return hipMalloc((void **)p, (n ? n : 1) * sizeof(T)); }
+
+void fill_params(const nm_ctx *c, KParams &p)
+{
+    std::memset(&p, 0, sizeof p);
+    p.N = c->N; p.nslots = c->nslots; p.slot0 = c->slot0;
+    p.nstps = c->cfg.nstps; p.bulk = c->cfg.bulk; p.iter_revert = c->cfg.iter_revert;
+    p.maxnb = c->maxnb;
+    p.seed = c->cfg.seed; p.step = c->step;
+    p.ppos = c->cfg.ppos; p.pvol = c->cfg.pvol; p.lat = c->lat; p.mass = c->mass;
+    p.kB = c->kB; p.mvv2e = c->mvv2e; p.ftm2v = c->ftm2v; p.nktv2p = c->nktv2p;
+    p.rc = 2.5; p.skin = 0.3;
+    p.x = c->d_x; p.v = c->d_v; p.box = c->d_box; p.steps = c->d_steps; p.therm = c->d_therm;
+    p.count = c->d_count; p.ratio = c->d_ratio; p.slot2buf = c->d_slot2buf;
+    p.et = c->d_et; p.pf = c->d_pf; p.tq = c->d_tq;
+    p.status = c->d_status; p.stats = c->d_stats;
+    p.tape = c->d_tape; p.tape_off = c->d_tape_off;
+    p.nbr_g = c->d_nbr; p.aux_g = c->d_aux;
+}
+
+template <class C>
+hipError_t launch_block(const nm_ctx *c, const KParams &p)
+{
+    hipLaunchKernelGGL(nm_block_kernel<C>, dim3(c->nslots), dim3(C::BLOCK), c->lds_bytes, c->stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_kind(const nm_ctx *c, const KParams &p)
+{
+    switch (c->kind) {
+    case 0: return launch_block<CfgSmall>(c, p);
+    case 1: return launch_block<CfgMid>(c, p);
+    default: return launch_block<CfgLarge>(c, p);
+    }
+}
+
+// drain one event pair into the timing accumulators
+void harvest(nm_ctx *c, EvPair &e)
+{
+    if (!e.used) return;
+    hipEventSynchronize(e.b);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { c->total_ms += ms; c->launches += 1; }
+    e.used = false;
+}
+
+int check_status(nm_ctx *c)
+{
+    std::vector<int> st(c->nslots);
+    if (hipMemcpy(st.data(), c->d_status, sizeof(int) * c->nslots, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(c, NM_ERR_HIP, "status readback failed");
+    for (int k = 0; k < c->nslots; ++k)
+        if (st[k]) {
+            char buf[256];
+            std::snprintf(buf, sizeof buf,
+                          "replica slot %d (global %d) left the supported regime:%s%s%s%s", k, c->slot0 + k,
+                          (st[k] & ST_LIST_OVERFLOW) ? " neighbour list overflow;" : "",
+                          (st[k] & ST_BOX_TOO_SMALL) ? " box edge < 2*rc (minimum image invalid);" : "",
+                          (st[k] & ST_TAPE_EXHAUSTED) ? " rng tape exhausted;" : "",
+                          (st[k] & ST_NONFINITE) ? " non-finite energy;" : "");
+            return fail(c, NM_ERR_STATE, buf);
+        }
+    return NM_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *nm_last_error(const nm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+int nm_nslots(const nm_ctx *ctx) { return ctx ? ctx->nslots : NM_ERR_ARG; }
+int nm_natoms(const nm_ctx *ctx) { return ctx ? ctx->N : NM_ERR_ARG; }
+
+int nm_create(const nm_config *cfg, nm_ctx **out)
+{
+    if (!cfg || !out) return fail(nullptr, NM_ERR_ARG, "nm_create: null argument");
+    *out = nullptr;
+    if (cfg->size != (int32_t)sizeof(nm_config)) return fail(nullptr, NM_ERR_ARG, "nm_create: nm_config size mismatch (ABI)");
+    if (cfg->natoms < 2 || cfg->natoms > 2048) return fail(nullptr, NM_ERR_ARG, "nm_create: natoms must be in [2, 2048]");
+    if (cfg->np < 1 || cfg->nt < 1 || cfg->nrows < 1 || cfg->row0 < 0 || cfg->row0 + cfg->nrows > cfg->np)
+        return fail(nullptr, NM_ERR_ARG, "nm_create: bad grid / row range");
+    if (!cfg->P || !cfg->T) return fail(nullptr, NM_ERR_ARG, "nm_create: P and T grids are required");
+    if (cfg->nstps < 1 || cfg->ppos < 0 || cfg->pvol < 0 || cfg->ppos + cfg->pvol > 1.0)
+        return fail(nullptr, NM_ERR_ARG, "nm_create: bad move parameters");
+    if (cfg->element != NM_EL_LJ)
+        return fail(nullptr, NM_ERR_UNSUPPORTED, "nm_create: only element LJ has a device force kernel in this build");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, NM_ERR_HIP, "nm_create: no HIP device available (this engine has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, NM_ERR_ARG, "nm_create: device ordinal out of range");
+
+    nm_ctx *c = new nm_ctx();
+    c->cfg = *cfg;
+    c->N = cfg->natoms;
+    c->nslots = cfg->nrows * cfg->nt;
+    c->slot0 = cfg->row0 * cfg->nt;
+    c->step = 0;
+    c->trace_on = 0; c->trace_mod = 0; c->trace_cap = 0; c->xtape_n = 0;
+    c->ev_next = 0; c->launches = 0; c->total_ms = 0.0;
+    // material tables, remcmc:873-893
+    c->lat = 1.122; c->mass = 1.0; c->kB = 1.0; c->mvv2e = 1.0; c->ftm2v = 1.0; c->nktv2p = 1.0;
+
+    // init_constant (remcmc:114-132) in float64 on the float32-rounded grid values (NumPy-1.x promotion)
+    c->h_et.resize(c->nslots); c->h_pf.resize(c->nslots); c->h_tq.resize(c->nslots);
+    for (int k = 0; k < c->nslots; ++k) {
+        const int i = cfg->row0 + k / cfg->nt, j = k % cfg->nt;
+        const double Pi = (double)cfg->P[i], Tj = (double)cfg->T[j];
+        const double kb = 1.0;
+        c->h_et[k] = kb * Tj;
+        c->h_pf[k] = Pi / (kb * Tj);
+        c->h_tq[k] = Tj;
+    }
+
+    if (c->N <= 256) { c->kind = 0; c->maxnb = 160; }
+    else if (c->N <= 864) { c->kind = 1; c->maxnb = 160; }
+    else { c->kind = 2; c->maxnb = 160; }
+    Layout lay = c->kind == 0 ? make_layout<CfgSmall>(c->N, c->maxnb)
+               : c->kind == 1 ? make_layout<CfgMid>(c->N, c->maxnb) : make_layout<CfgLarge>(c->N, c->maxnb);
+    c->lds_bytes = lay.total;
+    c->aux_doubles = lay.aux_doubles;
+
+#define CHK(call)                                                                                     \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            fail(nullptr, NM_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));             \
+            delete c;                                                                                 \
+            return NM_ERR_HIP;                                                                        \
+        }                                                                                             \
+    } while (0)
+    CHK(hipSetDevice(cfg->device));
+    CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t ns = c->nslots, n3 = (size_t)3 * c->N;
+    CHK(dalloc(&c->d_x, ns * n3)); CHK(dalloc(&c->d_v, ns * n3));
+    CHK(dalloc(&c->d_box, ns)); CHK(dalloc(&c->d_steps, ns * 3)); CHK(dalloc(&c->d_therm, ns * 5));
+    CHK(dalloc(&c->d_count, ns * 6)); CHK(dalloc(&c->d_ratio, ns * 3));
+    CHK(dalloc(&c->d_et, ns)); CHK(dalloc(&c->d_pf, ns)); CHK(dalloc(&c->d_tq, ns));
+    CHK(dalloc(&c->d_stats, ns * NM_STATS_COLS));
+    CHK(dalloc(&c->d_slot2buf, ns)); CHK(dalloc(&c->d_status, ns)); CHK(dalloc(&c->d_nswaps, 1));
+    CHK(dalloc(&c->d_evalU, ns)); CHK(dalloc(&c->d_evalW, ns)); CHK(dalloc(&c->d_evalF, ns * n3));
+    const int npairs = cfg->nrows * cfg->nt * (cfg->nt - 1) / 2;
+    CHK(dalloc(&c->d_xcrit, (size_t)npairs)); CHK(dalloc(&c->d_xtape, (size_t)npairs));
+    c->d_tape = nullptr; c->d_tape_off = nullptr; c->d_trace = nullptr; c->d_nbr = nullptr; c->d_aux = nullptr;
+    if (c->kind != 0) CHK(hipMalloc(&c->d_nbr, ns * (size_t)c->maxnb * c->N * sizeof(unsigned short)));
+    if (c->aux_doubles) CHK(dalloc(&c->d_aux, ns * c->aux_doubles));
+    CHK(hipMemset(c->d_x, 0, ns * n3 * sizeof(double))); CHK(hipMemset(c->d_v, 0, ns * n3 * sizeof(double)));
+    CHK(hipMemset(c->d_box, 0, ns * sizeof(double))); CHK(hipMemset(c->d_steps, 0, ns * 3 * sizeof(double)));
+    CHK(hipMemset(c->d_therm, 0, ns * 5 * sizeof(double))); CHK(hipMemset(c->d_count, 0, ns * 6 * sizeof(double)));
+    CHK(hipMemset(c->d_ratio, 0, ns * 3 * sizeof(float))); CHK(hipMemset(c->d_stats, 0, ns * NM_STATS_COLS * sizeof(double)));
+    CHK(hipMemset(c->d_status, 0, ns * sizeof(int))); CHK(hipMemset(c->d_nswaps, 0, sizeof(int)));
+    std::vector<int> ident(ns);
+    for (size_t k = 0; k < ns; ++k) ident[k] = (int)k;
+    CHK(hipMemcpy(c->d_slot2buf, ident.data(), ns * sizeof(int), hipMemcpyHostToDevice));
+    CHK(hipMemcpy(c->d_et, c->h_et.data(), ns * sizeof(double), hipMemcpyHostToDevice));
+    CHK(hipMemcpy(c->d_pf, c->h_pf.data(), ns * sizeof(double), hipMemcpyHostToDevice));
+    CHK(hipMemcpy(c->d_tq, c->h_tq.data(), ns * sizeof(double), hipMemcpyHostToDevice));
+    // dynamic LDS above 64 KiB has to be requested per kernel
+    if (c->kind == 0) CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+    else if (c->kind == 1) CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgMid>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+    else CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgLarge>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+    c->ev.resize(32);
+    for (auto &e : c->ev) { CHK(hipEventCreate(&e.a)); CHK(hipEventCreate(&e.b)); e.used = false; }
+#undef CHK
+    *out = c;
+    return NM_OK;
+}
+
+int nm_destroy(nm_ctx *c)
+{
+    if (!c) return NM_ERR_ARG;
+    hipSetDevice(c->cfg.device);
+    hipStreamSynchronize(c->stream);
+    for (auto &e : c->ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    void *ptrs[] = { c->d_x, c->d_v, c->d_box, c->d_steps, c->d_therm, c->d_count, c->d_ratio, c->d_et, c->d_pf, c->d_tq,
+                     c->d_stats, c->d_slot2buf, c->d_status, c->d_nswaps, c->d_evalU, c->d_evalW, c->d_evalF, c->d_xcrit,
+                     c->d_xtape, c->d_tape, c->d_tape_off, c->d_trace, c->d_nbr, c->d_aux };
+    for (void *q : ptrs) if (q) hipFree(q);
+    hipStreamDestroy(c->stream);
+    delete c;
+    return NM_OK;
+}
+
+int nm_get_const(const nm_ctx *c, double *et, double *pf)
+{
+    if (!c) return NM_ERR_ARG;
+    if (et) std::memcpy(et, c->h_et.data(), sizeof(double) * c->nslots);
+    if (pf) std::memcpy(pf, c->h_pf.data(), sizeof(double) * c->nslots);
+    return NM_OK;
+}
+
+int nm_set_step(nm_ctx *c, uint32_t step)
+{
+    if (!c) return NM_ERR_ARG;
+    c->step = step;
+    return NM_OK;
+}
+
+static int slot_map(nm_ctx *c, std::vector<int> &m)
+{
+    m.resize(c->nslots);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(m.data(), c->d_slot2buf, sizeof(int) * c->nslots, hipMemcpyDeviceToHost));
+    return NM_OK;
+}
+
+int nm_set_state(nm_ctx *c, int k0, int nk, const double *x, const double *v, const double *box, const double *dxdvdt)
+{
+    if (!c || k0 < 0 || nk < 0 || k0 + nk > c->nslots) return fail(c, NM_ERR_ARG, "nm_set_state: slot range");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    std::vector<int> m;
+    int rc = slot_map(c, m);
+    if (rc) return rc;
+    const size_t n3 = (size_t)3 * c->N;
+    for (int q = 0; q < nk; ++q) {
+        const int b = m[k0 + q];
+        if (x) HIPCHK(c, hipMemcpy(c->d_x + b * n3, x + q * n3, n3 * sizeof(double), hipMemcpyHostToDevice));
+        if (v) HIPCHK(c, hipMemcpy(c->d_v + b * n3, v + q * n3, n3 * sizeof(double), hipMemcpyHostToDevice));
+        if (box) {
+            HIPCHK(c, hipMemcpy(c->d_box + b, box + q, sizeof(double), hipMemcpyHostToDevice));
+            const double vol = std::pow(box[q], 3.0);
+            HIPCHK(c, hipMemcpy(c->d_therm + 5 * (size_t)b + 4, &vol, sizeof(double), hipMemcpyHostToDevice));
+        }
+        if (dxdvdt) HIPCHK(c, hipMemcpy(c->d_steps + 3 * (size_t)b, dxdvdt + 3 * q, 3 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return NM_OK;
+}
+
+int nm_get_state(nm_ctx *c, int k0, int nk, double *x, double *v, double *box, double *dxdvdt)
+{
+    if (!c || k0 < 0 || nk < 0 || k0 + nk > c->nslots) return fail(c, NM_ERR_ARG, "nm_get_state: slot range");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    std::vector<int> m;
+    int rc = slot_map(c, m);
+    if (rc) return rc;
+    const size_t n3 = (size_t)3 * c->N;
+    for (int q = 0; q < nk; ++q) {
+        const int b = m[k0 + q];
+        if (x) HIPCHK(c, hipMemcpy(x + q * n3, c->d_x + b * n3, n3 * sizeof(double), hipMemcpyDeviceToHost));
+        if (v) HIPCHK(c, hipMemcpy(v + q * n3, c->d_v + b * n3, n3 * sizeof(double), hipMemcpyDeviceToHost));
+        if (box) HIPCHK(c, hipMemcpy(box + q, c->d_box + b, sizeof(double), hipMemcpyDeviceToHost));
+        if (dxdvdt) HIPCHK(c, hipMemcpy(dxdvdt + 3 * q, c->d_steps + 3 * (size_t)b, 3 * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return check_status(c);
+}
+
+int nm_run_block(nm_ctx *c, int mod)
+{
+    if (!c || mod < 0) return fail(c, NM_ERR_ARG, "nm_run_block: bad argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    KParams p;
+    fill_params(c, p);
+    p.mod = mod;
+    if (c->trace_on) {
+        const size_t need = (size_t)c->nslots * mod * NM_TRACE_COLS;
+        if (need > c->trace_cap) {
+            if (c->d_trace) HIPCHK(c, hipFree(c->d_trace));
+            c->d_trace = nullptr;
+            HIPCHK(c, dalloc(&c->d_trace, need));
+            c->trace_cap = need;
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_trace, 0, need * sizeof(double), c->stream));
+        p.trace = c->d_trace;
+        c->trace_mod = mod;
+    }
+    EvPair &e = c->ev[c->ev_next];
+    harvest(c, e);
+    HIPCHK(c, hipEventRecord(e.a, c->stream));
+    HIPCHK(c, launch_kind(c, p));
+    HIPCHK(c, hipEventRecord(e.b, c->stream));
+    e.used = true;
+    c->ev_next = (c->ev_next + 1) % (int)c->ev.size();
+    return NM_OK;
+}
+
+int nm_get_thermo(nm_ctx *c, double *rows)
+{
+    if (!c || !rows) return fail(c, NM_ERR_ARG, "nm_get_thermo: null argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    std::vector<int> m;
+    int rc = slot_map(c, m);
+    if (rc) return rc;
+    const size_t ns = c->nslots;
+    std::vector<double> th(ns * 5), st(ns * 3), cn(ns * 6);
+    std::vector<float> ra(ns * 3);
+    HIPCHK(c, hipMemcpy(th.data(), c->d_therm, th.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(st.data(), c->d_steps, st.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(cn.data(), c->d_count, cn.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ra.data(), c->d_ratio, ra.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < ns; ++k) {
+        const int b = m[k];
+        double *r = rows + k * NM_THERMO_COLS;
+        r[0] = th[5 * b]; r[1] = th[5 * b + 1]; r[2] = th[5 * b + 2]; r[3] = th[5 * b + 3]; r[4] = th[5 * b + 4];
+        r[5] = st[3 * b]; r[6] = st[3 * b + 1]; r[7] = st[3 * b + 2];
+        for (int q = 0; q < 6; ++q) r[8 + q] = cn[6 * k + q];
+        for (int q = 0; q < 3; ++q) r[14 + q] = (double)ra[3 * k + q];
+    }
+    return check_status(c);
+}
+
+int nm_adapt(nm_ctx *c)
+{
+    if (!c) return NM_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    hipLaunchKernelGGL(nm_adapt_kernel, dim3((c->nslots + 63) / 64), dim3(64), 0, c->stream, c->nslots, c->d_slot2buf,
+                       c->d_steps, c->d_count, c->d_ratio);
+    HIPCHK(c, hipGetLastError());
+    return NM_OK;
+}
+
+int nm_exchange(nm_ctx *c, int *nswaps)
+{
+    if (!c) return NM_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipMemsetAsync(c->d_nswaps, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(nm_exchange_kernel, dim3((c->cfg.nrows + 63) / 64), dim3(64), 0, c->stream, c->cfg.nrows, c->cfg.nt,
+                       c->cfg.row0, c->cfg.seed, c->step, c->d_slot2buf, c->d_therm, c->d_et, c->d_pf,
+                       c->xtape_n ? c->d_xtape : nullptr, c->d_xcrit, c->d_nswaps);
+    HIPCHK(c, hipGetLastError());
+    if (nswaps) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(nswaps, c->d_nswaps, sizeof(int), hipMemcpyDeviceToHost));
+    }
+    return NM_OK;
+}
+
+int nm_synchronize(nm_ctx *c)
+{
+    if (!c) return NM_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_status(c);
+}
+
+int nm_timing_reset(nm_ctx *c)
+{
+    if (!c) return NM_ERR_ARG;
+    for (auto &e : c->ev) harvest(c, e);
+    c->launches = 0; c->total_ms = 0.0;
+    return NM_OK;
+}
+
+int nm_timing_get(nm_ctx *c, int *launches, double *total_ms)
+{
+    if (!c) return NM_ERR_ARG;
+    for (auto &e : c->ev) harvest(c, e);
+    if (launches) *launches = c->launches;
+    if (total_ms) *total_ms = c->total_ms;
+    return NM_OK;
+}
+
+int nm_stats_get(nm_ctx *c, double *stats, int reset)
+{
+    if (!c || !stats) return fail(c, NM_ERR_ARG, "nm_stats_get: null argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)c->nslots * NM_STATS_COLS;
+    HIPCHK(c, hipMemcpy(stats, c->d_stats, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(c, hipMemset(c->d_stats, 0, n * sizeof(double)));
+    return NM_OK;
+}
+
+int nm_eval(nm_ctx *c, double *U, double *W, double *f)
+{
+    if (!c || !U || !W) return fail(c, NM_ERR_ARG, "nm_eval: null argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    KParams p;
+    fill_params(c, p);
+    p.eval_only = 1; p.tape = nullptr;
+    p.evalU = c->d_evalU; p.evalW = c->d_evalW; p.evalF = f ? c->d_evalF : nullptr;
+    HIPCHK(c, launch_kind(c, p));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t ns = c->nslots;
+    HIPCHK(c, hipMemcpy(U, c->d_evalU, ns * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(W, c->d_evalW, ns * sizeof(double), hipMemcpyDeviceToHost));
+    if (f) HIPCHK(c, hipMemcpy(f, c->d_evalF, ns * 3 * c->N * sizeof(double), hipMemcpyDeviceToHost));
+    return check_status(c);
+}
+
+int nm_set_rng_tape(nm_ctx *c, const double *tape, const int *offsets)
+{
+    if (!c) return NM_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->d_tape) { HIPCHK(c, hipFree(c->d_tape)); c->d_tape = nullptr; }
+    if (c->d_tape_off) { HIPCHK(c, hipFree(c->d_tape_off)); c->d_tape_off = nullptr; }
+    if (!tape || !offsets) return NM_OK;
+    const int total = offsets[c->nslots];
+    if (total < 0) return fail(c, NM_ERR_ARG, "nm_set_rng_tape: bad offsets");
+    HIPCHK(c, dalloc(&c->d_tape, (size_t)total));
+    HIPCHK(c, dalloc(&c->d_tape_off, (size_t)c->nslots + 1));
+    HIPCHK(c, hipMemcpy(c->d_tape, tape, sizeof(double) * total, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_tape_off, offsets, sizeof(int) * (c->nslots + 1), hipMemcpyHostToDevice));
+    return NM_OK;
+}
+
+int nm_set_exchange_tape(nm_ctx *c, const double *tape, int n)
+{
+    if (!c) return NM_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int npairs = c->cfg.nrows * c->cfg.nt * (c->cfg.nt - 1) / 2;
+    if (!tape) { c->xtape_n = 0; return NM_OK; }
+    if (n != npairs) return fail(c, NM_ERR_ARG, "nm_set_exchange_tape: need one uniform per pair of the sweep");
+    HIPCHK(c, hipMemcpy(c->d_xtape, tape, sizeof(double) * n, hipMemcpyHostToDevice));
+    c->xtape_n = n;
+    return NM_OK;
+}
+
+int nm_set_trace(nm_ctx *c, int enable)
+{
+    if (!c) return NM_ERR_ARG;
+    c->trace_on = enable ? 1 : 0;
+    return NM_OK;
+}
+
+int nm_get_trace(nm_ctx *c, double *trace, int mod)
+{
+    if (!c || !trace) return fail(c, NM_ERR_ARG, "nm_get_trace: null argument");
+    if (!c->d_trace || mod != c->trace_mod) return fail(c, NM_ERR_ARG, "nm_get_trace: no trace of that length recorded");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(trace, c->d_trace, (size_t)c->nslots * mod * NM_TRACE_COLS * sizeof(double), hipMemcpyDeviceToHost));
+    return NM_OK;
+}
+
+int nm_get_perm(nm_ctx *c, int *perm)
+{
+    if (!c || !perm) return fail(c, NM_ERR_ARG, "nm_get_perm: null argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(perm, c->d_slot2buf, sizeof(int) * c->nslots, hipMemcpyDeviceToHost));
+    return NM_OK;
+}
+
+int nm_get_exchange_crit(nm_ctx *c, double *crit, int n)
+{
+    if (!c || !crit) return fail(c, NM_ERR_ARG, "nm_get_exchange_crit: null argument");
+    const int npairs = c->cfg.nrows * c->cfg.nt * (c->cfg.nt - 1) / 2;
+    if (n != npairs) return fail(c, NM_ERR_ARG, "nm_get_exchange_crit: wrong pair count");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(crit, c->d_xcrit, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return NM_OK;
+}
+
+} // extern "C"

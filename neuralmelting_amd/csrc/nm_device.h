@@ -1,0 +1,112 @@
+// nm_device.h — device-side building blocks of the MI355X (gfx950) NPT-HMC engine.
+//
+// One workgroup owns one replica for a whole block of MOD moves.  Coordinates, velocities, forces,
+// the saved copies for Metropolis rejection and (for N <= 256) the byte-indexed Verlet list live
+// in LDS for the entire block; HBM is touched once at block start and once at block end.
+// Wave width is 64 throughout (CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nm {
+
+// RNG stream ids: counter = (index, stream, tag, step), key = (seed, global slot).  DESIGN.md §RNG.
+enum : uint32_t { S_ROLL = 0, S_ACC = 1, S_VOL = 2, S_DISP_XY = 3, S_DISP_Z = 4, S_VEL_A = 5, S_VEL_B = 6,
+                  S_EXCH = 7, S_ITER_XY = 8, S_ITER_Z = 9, S_ITER_ACC = 10 };
+
+// status bits per slot
+enum : int { ST_LIST_OVERFLOW = 1, ST_BOX_TOO_SMALL = 2, ST_TAPE_EXHAUSTED = 4, ST_NONFINITE = 8 };
+
+struct KParams {
+    int N, nslots, slot0;          // atoms, local replicas, global index of local slot 0
+    int mod, nstps, bulk, iter_revert;
+    int eval_only;                 // nm_eval: evaluate the loaded states and leave
+    int maxnb;                     // neighbour slots per atom
+    uint32_t seed, step;
+    double ppos, pvol, lat, mass;
+    double kB, mvv2e, ftm2v, nktv2p;
+    double rc, skin;
+    // per buffer
+    double *x, *v, *box, *steps, *therm;
+    // per slot
+    double *count;
+    float *ratio;
+    const int *slot2buf;
+    const double *et, *pf, *tq;
+    int *status;
+    double *stats;
+    const double *tape;
+    const int *tape_off;
+    double *trace;                 // [slot][mod][4] or null
+    double *evalU, *evalW, *evalF; // nm_eval outputs
+    void *nbr_g;                   // global neighbour lists (N > 256): [slot][maxnb*N] uint16
+    double *aux_g;                 // global spill of the saved copies (large N): [slot][AUX_DOUBLES(N)]
+};
+
+// ------------------------------------------------------------------------------------------ Philox4x32-10
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&o)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+__device__ __forceinline__ double u01(uint32_t hi, uint32_t lo)
+{
+    const unsigned long long w = ((unsigned long long)hi << 32) | (unsigned long long)lo;
+    return (double)(w >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// value of float('%f' % x): the reference hands box edge, timestep, temperature and displacement
+// amplitude to LAMMPS through '%f' strings (remcmc:466,483,571,604,607)
+__device__ __forceinline__ double q6(double x)
+{
+    const double p = x * 1.0e6;
+    double n = rint(p);
+    if (fabs(p - n) == 0.5) {
+        const double e = fma(x, 1.0e6, -p);
+        if (e > 0.0) n = floor(p) + 1.0;
+        else if (e < 0.0) n = floor(p);
+    }
+    return n / 1.0e6;
+}
+
+// ------------------------------------------------------------------------------------------ reductions
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v; // xor butterfly: every lane holds the bit-identical total
+}
+
+// Sum NV values over the workgroup; every thread returns the same bits (fixed order: butterfly inside a
+// wave, then waves 0..NW-1).  `red` has 2*NW*NVMAX doubles and is used in two alternating halves so that
+// one barrier per reduction suffices.
+template <int NV, int NW, int NVMAX>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *red, int &parity)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double *r = red + parity * (NW * NVMAX);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const double s = wave_sum(v[q]);
+        if (lane == 0) r[wv * NVMAX + q] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        double s = 0.0;
+        for (int w = 0; w < NW; ++w) s += r[w * NVMAX + q];
+        v[q] = s;
+    }
+    parity ^= 1;
+}
+
+} // namespace nm

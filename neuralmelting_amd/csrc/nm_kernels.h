@@ -1,0 +1,662 @@
+// nm_kernels.h — the persistent per-replica block kernel (gen_sample, remcmc:665-691) and the small
+// adapt / exchange kernels (remcmc:726-745, 776-803) for gfx950.
+//
+// Mapping to the reference (every LAMMPS command the reference issues is re-implemented here):
+//   setup()            "run 0"            remcmc:469,484,496,527,573,588,608,633
+//   eval()             pair_style lj/cut 2.5 energy/force/virial over a Verlet list kept in LDS
+//   bulk_pmc()         bulk_position_mc   remcmc:477-502  (displace_atoms all random ...)
+//   iter_pmc()         iter_position_mc   remcmc:505-549
+//   vmc()              volume_mc          remcmc:552-595  (change_box ... + scaled scatter)
+//   hmc()              hamiltonian_mc     remcmc:598-640  (velocity create/zero, fix nve run NSTPS)
+//   block end          lammps_extract     remcmc:377-391 + ratios remcmc:685-688
+#pragma once
+#include "nm_device.h"
+
+namespace nm {
+
+constexpr int NVMAX = 10; // widest block reduction (angular momentum 3 + inertia 6)
+
+template <int BLOCK_, int TPA_, typename IdxT_, bool LIST_LDS_, bool SAVE_LDS_>
+struct Cfg {
+    static constexpr int BLOCK = BLOCK_, TPA = TPA_, NW = BLOCK_ / 64, G = BLOCK_ / TPA_;
+    static constexpr bool LIST_LDS = LIST_LDS_, SAVE_LDS = SAVE_LDS_;
+    using IdxT = IdxT_;
+};
+
+struct Layout {
+    size_t pos, vel, frc, sav, savv, x0, red, cnt, img, simg, nbr, total; // byte offsets into dynamic LDS
+    size_t aux_doubles;                                                     // per-slot global spill (doubles)
+};
+
+template <class C>
+__host__ __device__ inline Layout make_layout(int N, int maxnb)
+{
+    Layout l{};
+    size_t o = 0;
+    const size_t a3 = (size_t)3 * N * sizeof(double);
+    l.pos = o; o += a3;
+    l.vel = o; o += a3;
+    l.frc = o; o += a3;
+    if (C::SAVE_LDS) { l.sav = o; o += a3; l.savv = o; o += a3; l.x0 = o; o += a3; }
+    l.red = o; o += (size_t)2 * C::NW * NVMAX * sizeof(double);
+    l.cnt = o; o += (((size_t)N * sizeof(unsigned short)) + 7) & ~(size_t)7;
+    l.img = o; o += (((size_t)3 * N) + 7) & ~(size_t)7;
+    if (C::SAVE_LDS) { l.simg = o; o += (((size_t)3 * N) + 7) & ~(size_t)7; }
+    if (C::LIST_LDS) { l.nbr = o; o += (((size_t)maxnb * N * sizeof(typename C::IdxT)) + 7) & ~(size_t)7; }
+    l.total = o;
+    // spill: sav, savv, x0 (9N doubles) + saved images (3N bytes, rounded up to doubles)
+    l.aux_doubles = C::SAVE_LDS ? 0 : (size_t)9 * N + ((size_t)3 * N + 7) / 8;
+    return l;
+}
+
+template <class C>
+struct Replica {
+    using IdxT = typename C::IdxT;
+    static constexpr int BLOCK = C::BLOCK, TPA = C::TPA, NW = C::NW, G = C::G;
+
+    const KParams &p;
+    const int tid, N, gslot;
+    double *px, *py, *pz, *vx, *vy, *vz, *fx, *fy, *fz;
+    double *sx, *sy, *sz, *svx, *svy, *svz, *x0, *y0, *z0;
+    signed char *im, *sim;
+    unsigned short *cnt;
+    IdxT *nbr;
+    double *red;
+    int parity = 0;
+    // block-uniform scalars
+    double L = 0.0, L0 = 0.0, U = 0.0, W = 0.0;
+    bool list_ok = false, fresh = false;
+    int status = 0;
+    const double *tape = nullptr;
+    int tpos = 0, tlen = 0;
+    double st_evals = 0.0, st_rebuilds = 0.0, st_eevals = 0.0, st_pairs = 0.0;
+
+    __device__ Replica(const KParams &p_, unsigned char *smem, int slot)
+        : p(p_), tid(threadIdx.x), N(p_.N), gslot(p_.slot0 + slot)
+    {
+        const Layout l = make_layout<C>(N, p.maxnb);
+        px = (double *)(smem + l.pos); py = px + N; pz = py + N;
+        vx = (double *)(smem + l.vel); vy = vx + N; vz = vy + N;
+        fx = (double *)(smem + l.frc); fy = fx + N; fz = fy + N;
+        red = (double *)(smem + l.red);
+        cnt = (unsigned short *)(smem + l.cnt);
+        im = (signed char *)(smem + l.img);
+        if constexpr (C::SAVE_LDS) {
+            sx = (double *)(smem + l.sav); svx = (double *)(smem + l.savv); x0 = (double *)(smem + l.x0);
+            sim = (signed char *)(smem + l.simg);
+        } else {
+            double *a = p.aux_g + (size_t)slot * l.aux_doubles;
+            sx = a; svx = a + 3 * (size_t)N; x0 = a + 6 * (size_t)N;
+            sim = (signed char *)(a + 9 * (size_t)N);
+        }
+        sy = sx + N; sz = sy + N; svy = svx + N; svz = svy + N; y0 = x0 + N; z0 = y0 + N;
+        if constexpr (C::LIST_LDS) nbr = (IdxT *)(smem + l.nbr);
+        else nbr = (IdxT *)p.nbr_g + (size_t)slot * p.maxnb * N;
+        if (p.tape) { tape = p.tape + p.tape_off[slot]; tlen = p.tape_off[slot + 1] - p.tape_off[slot]; }
+    }
+
+    // ------------------------------------------------------------------ random draws
+    __device__ __forceinline__ double draw_scalar(uint32_t stream, uint32_t m, uint32_t index)
+    {
+        if (tape) { // test-only: uniforms recorded from the reference's np.random stream
+            double v = 2.0;
+            if (tpos < tlen) v = tape[tpos]; else status |= ST_TAPE_EXHAUSTED;
+            ++tpos;
+            return v;
+        }
+        uint32_t o[4];
+        philox4x32_10(index, stream, m, p.step, p.seed, (uint32_t)gslot, o);
+        return u01(o[0], o[1]);
+    }
+    __device__ __forceinline__ uint32_t draw_tag(uint32_t m)
+    {
+        if (tape) { // np.random.randint(1, 2**16), remcmc:482,603
+            uint32_t v = 0;
+            if (tpos < tlen) v = (uint32_t)(tape[tpos] * 65536.0); else status |= ST_TAPE_EXHAUSTED; // randint/65536
+            ++tpos;
+            return v;
+        }
+        return m;
+    }
+    // remcmc:487-500: metcrit = exp(-c); +inf -> reject without drawing; else accept iff u <= min(1, metcrit)
+    __device__ __forceinline__ bool metropolis(double c, uint32_t stream, uint32_t m, uint32_t index)
+    {
+        const double metcrit = exp(-c);
+        if (isinf(metcrit)) return false;
+        const double u = draw_scalar(stream, m, index);
+        const double mm = (metcrit != metcrit) ? metcrit : (metcrit < 1.0 ? metcrit : 1.0);
+        return u <= mm;
+    }
+
+    // ------------------------------------------------------------------ HBM <-> LDS
+    __device__ void load(int buf)
+    {
+        const double *gx = p.x + (size_t)buf * 3 * N, *gv = p.v + (size_t)buf * 3 * N;
+        for (int a = tid; a < 3 * N; a += BLOCK) { // coalesced interleaved read, de-interleave into SoA
+            const int i = a / 3, c = a - 3 * i;
+            (c == 0 ? px : c == 1 ? py : pz)[i] = gx[a];
+            (c == 0 ? vx : c == 1 ? vy : vz)[i] = gv[a];
+            im[a] = 0; // a new LAMMPS instance per block starts with zero image flags (remcmc:462-463)
+        }
+        __syncthreads();
+    }
+    __device__ void store(int buf)
+    {
+        __syncthreads();
+        double *gx = p.x + (size_t)buf * 3 * N, *gv = p.v + (size_t)buf * 3 * N;
+        for (int a = tid; a < 3 * N; a += BLOCK) {
+            const int i = a / 3, c = a - 3 * i;
+            gx[a] = (c == 0 ? px : c == 1 ? py : pz)[i];
+            gv[a] = (c == 0 ? vx : c == 1 ? vy : vz)[i];
+        }
+    }
+
+    // ------------------------------------------------------------------ per-atom elementwise phases
+    // Ownership: atom i belongs to thread i % BLOCK in every elementwise phase, so these need no barrier
+    // among themselves; eval() opens with one.
+    __device__ __forceinline__ void wrap1(double &x, signed char &ig)
+    {
+        if (x < 0.0 || x >= L) { // domain->remap
+            const double nb = floor(x / L);
+            x -= nb * L;
+            int d = (int)nb;
+            if (x >= L) { x -= L; d += 1; }
+            if (x < 0.0) x = 0.0;
+            ig = (signed char)(ig + d);
+        }
+    }
+    __device__ void wrap()
+    {
+        for (int i = tid; i < N; i += BLOCK) {
+            wrap1(px[i], im[3 * i]); wrap1(py[i], im[3 * i + 1]); wrap1(pz[i], im[3 * i + 2]);
+        }
+    }
+    __device__ void save(bool with_v)
+    {
+        for (int i = tid; i < N; i += BLOCK) {
+            sx[i] = px[i]; sy[i] = py[i]; sz[i] = pz[i];
+            sim[3 * i] = im[3 * i]; sim[3 * i + 1] = im[3 * i + 1]; sim[3 * i + 2] = im[3 * i + 2];
+            if (with_v) { svx[i] = vx[i]; svy[i] = vy[i]; svz[i] = vz[i]; }
+        }
+    }
+    __device__ void restore(bool with_v)
+    {
+        for (int i = tid; i < N; i += BLOCK) {
+            px[i] = sx[i]; py[i] = sy[i]; pz[i] = sz[i];
+            im[3 * i] = sim[3 * i]; im[3 * i + 1] = sim[3 * i + 1]; im[3 * i + 2] = sim[3 * i + 2];
+            if (with_v) { vx[i] = svx[i]; vy[i] = svy[i]; vz[i] = svz[i]; }
+        }
+        fresh = false;
+    }
+    __device__ double sum_mv2()
+    {
+        double s[1] = { 0.0 };
+        for (int i = tid; i < N; i += BLOCK) s[0] += p.mass * (vx[i] * vx[i] + vy[i] * vy[i] + vz[i] * vz[i]);
+        block_sum<1, NW, NVMAX>(s, red, parity);
+        return s[0];
+    }
+
+    // ------------------------------------------------------------------ Verlet list
+    // Wave-cooperative build: one wave per atom i, 64 candidate j per step, ballot compaction keeps the
+    // list sorted by j, so the list (and every sum over it) is independent of scheduling.
+    __device__ void rebuild()
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        const double invL = 1.0 / L, rl = p.rc + p.skin, rl2 = rl * rl;
+        int ovf = 0;
+        for (int i = wv; i < N; i += NW) {
+            const double xi = px[i], yi = py[i], zi = pz[i];
+            int base = 0;
+            for (int j0 = 0; j0 < N; j0 += 64) {
+                const int j = j0 + lane;
+                bool in = false;
+                if (j < N && j != i) {
+                    double dx = xi - px[j], dy = yi - py[j], dz = zi - pz[j];
+                    dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
+                    in = (dx * dx + dy * dy + dz * dz) < rl2;
+                }
+                const unsigned long long m = __ballot(in);
+                if (in) {
+                    const int r = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (r < p.maxnb) nbr[(size_t)r * N + i] = (IdxT)j;
+                }
+                base += __popcll(m);
+            }
+            if (base > p.maxnb) { ovf = 1; base = p.maxnb; }
+            if (lane == 0) cnt[i] = (unsigned short)base;
+        }
+        for (int i = tid; i < N; i += BLOCK) { x0[i] = px[i]; y0[i] = py[i]; z0[i] = pz[i]; }
+        L0 = L;
+        list_ok = true;
+        st_rebuilds += 1.0;
+        if (__syncthreads_or(ovf)) status |= ST_LIST_OVERFLOW;
+    }
+
+    // ------------------------------------------------------------------ lj/cut 2.5 energy, forces, virial
+    // pair_lj_cut: r2inv, r6inv, fpair = r6inv*(48 r6inv - 24)*r2inv, evdwl = r6inv*(4 r6inv - 4), no shift/tail.
+    // Full (both-direction) list: thread group (i, sub) owns f_i, no scatter, no atomics, fixed summation order.
+    __device__ void eval(bool want_e)
+    {
+        __syncthreads(); // positions written by their owners are visible; previous readers are done
+        if (!(L >= 2.0 * p.rc)) { status |= ST_BOX_TOO_SMALL; return; } // minimum-image limit
+        bool need = !list_ok;
+        const double invL = 1.0 / L;
+        if (!need) {
+            // the list built at (x0, L0) still covers every pair within rc of the affinely rescaled reference if
+            // max_i |x_i - (L/L0) x0_i| <= ((L/L0)(rc+skin) - rc)/2
+            const double sc = L / L0;
+            const double thr = 0.5 * (sc * (p.rc + p.skin) - p.rc), thr2 = thr * thr;
+            int bad = !(thr > 0.0);
+            for (int i = tid; i < N; i += BLOCK) {
+                double dx = px[i] - sc * x0[i], dy = py[i] - sc * y0[i], dz = pz[i] - sc * z0[i];
+                dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
+                if (dx * dx + dy * dy + dz * dz > thr2) bad = 1;
+            }
+            need = __syncthreads_or(bad);
+        }
+        if (need) rebuild();
+
+        const int g = tid / TPA, sub = tid - g * TPA;
+        const double rc2 = p.rc * p.rc;
+        double eacc = 0.0, wacc = 0.0, nacc = 0.0;
+        for (int i0 = 0; i0 < N; i0 += G) { // uniform trip count keeps the shuffles below convergent
+            const int i = i0 + g;
+            double ax = 0.0, ay = 0.0, az = 0.0, e = 0.0, w = 0.0, np = 0.0;
+            if (i < N) {
+                const double xi = px[i], yi = py[i], zi = pz[i];
+                const int c = cnt[i];
+                for (int s = sub; s < c; s += TPA) {
+                    const int j = nbr[(size_t)s * N + i];
+                    double dx = xi - px[j], dy = yi - py[j], dz = zi - pz[j];
+                    dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
+                    const double r2 = dx * dx + dy * dy + dz * dz;
+                    if (r2 < rc2) {
+                        const double r2i = 1.0 / r2;
+                        const double r6i = r2i * r2i * r2i;
+                        const double fp = r6i * (48.0 * r6i - 24.0) * r2i;
+                        ax += dx * fp; ay += dy * fp; az += dz * fp;
+                        e += r6i * (4.0 * r6i - 4.0);
+                        w += r2 * fp;
+                        np += 1.0;
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = TPA / 2; off >= 1; off >>= 1) {
+                ax += __shfl_xor(ax, off, 64); ay += __shfl_xor(ay, off, 64); az += __shfl_xor(az, off, 64);
+                if (want_e) { e += __shfl_xor(e, off, 64); w += __shfl_xor(w, off, 64); np += __shfl_xor(np, off, 64); }
+            }
+            if (i < N && sub == 0) { fx[i] = ax; fy[i] = ay; fz[i] = az; eacc += e; wacc += w; nacc += np; }
+        }
+        st_evals += 1.0;
+        if (want_e) {
+            double s[3] = { eacc, wacc, nacc };
+            block_sum<3, NW, NVMAX>(s, red, parity);
+            U = 0.5 * s[0]; W = 0.5 * s[1];
+            st_eevals += 1.0; st_pairs += 0.5 * s[2];
+            if (!(U == U) || isinf(U)) status |= ST_NONFINITE;
+        } else {
+            __syncthreads();
+        }
+        fresh = true;
+    }
+
+    // "run 0": remap atoms into the box, (re-neighbour,) forces and thermo.  Skips the evaluation when
+    // nothing moved since the last one (same U, W, f as the reference's repeated run 0).
+    __device__ void setup()
+    {
+        wrap();
+        if (!fresh) eval(true);
+    }
+
+    // ------------------------------------------------------------------ velocity commands (remcmc:604-606)
+    __device__ void zero_linear()
+    {
+        double s[3] = { 0.0, 0.0, 0.0 };
+        for (int i = tid; i < N; i += BLOCK) { s[0] += p.mass * vx[i]; s[1] += p.mass * vy[i]; s[2] += p.mass * vz[i]; }
+        block_sum<3, NW, NVMAX>(s, red, parity);
+        const double mt = p.mass * N;
+        const double cx = s[0] / mt, cy = s[1] / mt, cz = s[2] / mt;
+        for (int i = tid; i < N; i += BLOCK) { vx[i] -= cx; vy[i] -= cy; vz[i] -= cz; }
+    }
+    // velocity all create t seed dist gaussian: gaussians/sqrt(m) per atom id, COM momentum removed,
+    // rescaled to exactly t with dof = 3N-3 (LAMMPS velocity.cpp create(), defaults mom yes rot no)
+    __device__ void velocity_create(double t, uint32_t tag)
+    {
+        const double twopi = 6.283185307179586476925286766559;
+        const double fac = 1.0 / sqrt(p.mass);
+        for (int i = tid; i < N; i += BLOCK) {
+            uint32_t o[4], q[4];
+            philox4x32_10((uint32_t)i, S_VEL_A, tag, p.step, p.seed, (uint32_t)gslot, o);
+            philox4x32_10((uint32_t)i, S_VEL_B, tag, p.step, p.seed, (uint32_t)gslot, q);
+            const double u1 = u01(o[0], o[1]), u2 = u01(o[2], o[3]), u3 = u01(q[0], q[1]), u4 = u01(q[2], q[3]);
+            const double r1 = sqrt(-2.0 * log(1.0 - u1)), r2 = sqrt(-2.0 * log(1.0 - u3));
+            vx[i] = r1 * cos(twopi * u2) * fac;
+            vy[i] = r1 * sin(twopi * u2) * fac;
+            vz[i] = r2 * cos(twopi * u4) * fac;
+        }
+        zero_linear();
+        const double dof = 3.0 * N - 3.0;
+        const double tcur = sum_mv2() * p.mvv2e / (dof * p.kB);
+        const double sc = sqrt(t / tcur);
+        for (int i = tid; i < N; i += BLOCK) { vx[i] *= sc; vy[i] *= sc; vz[i] *= sc; }
+    }
+    // velocity all zero angular: omega = I^-1 L about the centre of mass of the unwrapped coordinates
+    __device__ void zero_angular()
+    {
+        const double m = p.mass;
+        double c[3] = { 0.0, 0.0, 0.0 };
+        for (int i = tid; i < N; i += BLOCK) {
+            c[0] += m * (px[i] + im[3 * i] * L); c[1] += m * (py[i] + im[3 * i + 1] * L); c[2] += m * (pz[i] + im[3 * i + 2] * L);
+        }
+        block_sum<3, NW, NVMAX>(c, red, parity);
+        const double mt = m * N;
+        const double cx = c[0] / mt, cy = c[1] / mt, cz = c[2] / mt;
+        double s[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // L(3), I00 I11 I22 I01 I12 I02
+        for (int i = tid; i < N; i += BLOCK) {
+            const double dx = px[i] + im[3 * i] * L - cx, dy = py[i] + im[3 * i + 1] * L - cy, dz = pz[i] + im[3 * i + 2] * L - cz;
+            s[0] += m * (dy * vz[i] - dz * vy[i]);
+            s[1] += m * (dz * vx[i] - dx * vz[i]);
+            s[2] += m * (dx * vy[i] - dy * vx[i]);
+            s[3] += m * (dy * dy + dz * dz);
+            s[4] += m * (dx * dx + dz * dz);
+            s[5] += m * (dx * dx + dy * dy);
+            s[6] -= m * dx * dy;
+            s[7] -= m * dy * dz;
+            s[8] -= m * dx * dz;
+        }
+        block_sum<9, NW, NVMAX>(s, red, parity);
+        const double I00 = s[3], I11 = s[4], I22 = s[5], I01 = s[6], I12 = s[7], I02 = s[8];
+        const double det = I00 * I11 * I22 + I01 * I12 * I02 + I02 * I01 * I12 - I00 * I12 * I12 - I01 * I01 * I22 - I02 * I11 * I02;
+        double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+        if (det > 0.0) {
+            const double i00 = I11 * I22 - I12 * I12, i01 = -(I01 * I22 - I02 * I12), i02 = I01 * I12 - I02 * I11;
+            const double i10 = -(I01 * I22 - I12 * I02), i11 = I00 * I22 - I02 * I02, i12 = -(I00 * I12 - I02 * I01);
+            const double i20 = I01 * I12 - I11 * I02, i21 = -(I00 * I12 - I01 * I02), i22 = I00 * I11 - I01 * I01;
+            w0 = (i00 * s[0] + i01 * s[1] + i02 * s[2]) / det;
+            w1 = (i10 * s[0] + i11 * s[1] + i12 * s[2]) / det;
+            w2 = (i20 * s[0] + i21 * s[1] + i22 * s[2]) / det;
+        }
+        for (int i = tid; i < N; i += BLOCK) {
+            const double dx = px[i] + im[3 * i] * L - cx, dy = py[i] + im[3 * i + 1] * L - cy, dz = pz[i] + im[3 * i + 2] * L - cz;
+            vx[i] -= w1 * dz - w2 * dy;
+            vy[i] -= w2 * dx - w0 * dz;
+            vz[i] -= w0 * dy - w1 * dx;
+        }
+    }
+
+    // ------------------------------------------------------------------ the moves
+    __device__ bool bulk_pmc(uint32_t m, double et, double dx, double &nt, double &na, double &crit)
+    {
+        nt += 1.0;
+        save(false);
+        const double U0 = U, W0 = W, pe = U / et;
+        const uint32_t tag = draw_tag(m);
+        const double a = q6(dx * p.lat);
+        for (int i = tid; i < N; i += BLOCK) { // displace_atoms all random a a a seed units box
+            uint32_t o[4], q[4];
+            philox4x32_10((uint32_t)i, S_DISP_XY, tag, p.step, p.seed, (uint32_t)gslot, o);
+            philox4x32_10((uint32_t)i, S_DISP_Z, tag, p.step, p.seed, (uint32_t)gslot, q);
+            px[i] += a * 2.0 * (u01(o[0], o[1]) - 0.5);
+            py[i] += a * 2.0 * (u01(o[2], o[3]) - 0.5);
+            pz[i] += a * 2.0 * (u01(q[0], q[1]) - 0.5);
+        }
+        fresh = false;
+        setup();
+        const double penew = U / et;
+        crit = penew - pe;
+        const bool acc = metropolis(crit, S_ACC, m, 0);
+        if (acc) na += 1.0;
+        else { restore(false); wrap(); U = U0; W = W0; }
+        return acc;
+    }
+
+    // single-particle energy difference against all other atoms (identical to the reference's difference of two
+    // full-system energies up to summation order)
+    __device__ void delta_single(int k, double ox, double oy, double oz, double nx, double ny, double nz, double &dE, double &dW)
+    {
+        const double invL = 1.0 / L, rc2 = p.rc * p.rc;
+        double s[2] = { 0.0, 0.0 };
+        for (int j = tid; j < N; j += BLOCK) {
+            if (j == k) continue;
+            const double xj = px[j], yj = py[j], zj = pz[j];
+            double dx = nx - xj, dy = ny - yj, dz = nz - zj;
+            dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
+            double r2 = dx * dx + dy * dy + dz * dz;
+            if (r2 < rc2) { const double r2i = 1.0 / r2, r6i = r2i * r2i * r2i; s[0] += r6i * (4.0 * r6i - 4.0); s[1] += r6i * (48.0 * r6i - 24.0); }
+            dx = ox - xj; dy = oy - yj; dz = oz - zj;
+            dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
+            r2 = dx * dx + dy * dy + dz * dz;
+            if (r2 < rc2) { const double r2i = 1.0 / r2, r6i = r2i * r2i * r2i; s[0] -= r6i * (4.0 * r6i - 4.0); s[1] -= r6i * (48.0 * r6i - 24.0); }
+        }
+        block_sum<2, NW, NVMAX>(s, red, parity);
+        dE = s[0]; dW = s[1];
+    }
+
+    __device__ int iter_pmc(uint32_t m, double et, double dx, double &nt, double &na, double &crit)
+    {
+        int nacc = 0;
+        wrap(); // one consistent remap at move start (image flags under iter PMC)
+        __syncthreads();
+        const double boxl = L;
+        for (int k = 0; k < N; ++k) {
+            nt += 1.0;
+            const double pe = U / et;
+            double u3[3];
+            if (tape) { u3[0] = draw_scalar(0, 0, 0); u3[1] = draw_scalar(0, 0, 0); u3[2] = draw_scalar(0, 0, 0); }
+            else {
+                uint32_t o[4], q[4];
+                philox4x32_10((uint32_t)k, S_ITER_XY, m, p.step, p.seed, (uint32_t)gslot, o);
+                philox4x32_10((uint32_t)k, S_ITER_Z, m, p.step, p.seed, (uint32_t)gslot, q);
+                u3[0] = u01(o[0], o[1]); u3[1] = u01(o[2], o[3]); u3[2] = u01(q[0], q[1]);
+            }
+            const double ox = px[k], oy = py[k], oz = pz[k];
+            double nx = ox + 2.0 * (u3[0] - 0.5) * dx * p.lat, ny = oy + 2.0 * (u3[1] - 0.5) * dx * p.lat, nz = oz + 2.0 * (u3[2] - 0.5) * dx * p.lat;
+            nx -= floor(nx / boxl) * boxl; ny -= floor(ny / boxl) * boxl; nz -= floor(nz / boxl) * boxl; // remcmc:524
+            double dE, dW;
+            delta_single(k, ox, oy, oz, nx, ny, nz, dE, dW);
+            const double Unew = U + dE;
+            const double de = Unew / et - pe;
+            const bool acc = metropolis(de, S_ITER_ACC, m, (uint32_t)k);
+            crit = de;
+            if (acc) { na += 1.0; ++nacc; }
+            if (acc || !p.iter_revert) { // reference: a rejected trial is not undone (remcmc:522,525,540 aliasing)
+                if (tid == (k % BLOCK)) { px[k] = nx; py[k] = ny; pz[k] = nz; }
+                U = Unew; W += dW;
+                fresh = false;
+            }
+            __syncthreads();
+        }
+        return nacc;
+    }
+
+    __device__ bool vmc(uint32_t m, double et, double pf, double dv, double &nt, double &na, double &crit)
+    {
+        nt += 1.0;
+        const double boxl = L, vol = pow(boxl, 3.0);
+        save(false);
+        const double U0 = U, W0 = W, pe = U / et;
+        const double u = draw_scalar(S_VOL, m, 0);
+        const double volnew = exp(log(vol) + 2.0 * (u - 0.5) * dv);
+        const double boxnew = cbrt(volnew);
+        const double scale = boxnew / boxl;
+        for (int i = tid; i < N; i += BLOCK) { px[i] = scale * sx[i]; py[i] = scale * sy[i]; pz[i] = scale * sz[i]; }
+        fresh = false;
+        L = q6(boxnew); // change_box ... %f
+        setup();
+        const double penew = U / et;
+        crit = (penew - pe) + pf * (volnew - vol) - (double)(N + 1) * log(volnew / vol); // remcmc:576
+        const bool acc = metropolis(crit, S_ACC, m, 0);
+        if (acc) na += 1.0;
+        else { L = q6(boxl); restore(false); wrap(); U = U0; W = W0; }
+        return acc;
+    }
+
+    __device__ bool hmc(uint32_t m, double et, double t, double dt, double &nt, double &na, double &crit)
+    {
+        nt += 1.0;
+        const uint32_t tag = draw_tag(m);
+        velocity_create(q6(t), tag);
+        zero_linear();
+        zero_angular();
+        const double h = q6(dt); // timestep %f
+        setup();
+        save(true);
+        const double U0 = U, W0 = W;
+        const double etot = U / et + 0.5 * p.mvv2e * sum_mv2() / et;
+        // run NSTPS: fix nve velocity-Verlet, no remap inside the run
+        const double dtfm = 0.5 * h * p.ftm2v / p.mass;
+        for (int s = 0; s < p.nstps; ++s) {
+            for (int i = tid; i < N; i += BLOCK) {
+                vx[i] += dtfm * fx[i]; vy[i] += dtfm * fy[i]; vz[i] += dtfm * fz[i];
+                px[i] += h * vx[i]; py[i] += h * vy[i]; pz[i] += h * vz[i];
+            }
+            eval(s == p.nstps - 1);
+            if (status & (ST_BOX_TOO_SMALL | ST_LIST_OVERFLOW)) return false;
+            for (int i = tid; i < N; i += BLOCK) { vx[i] += dtfm * fx[i]; vy[i] += dtfm * fy[i]; vz[i] += dtfm * fz[i]; }
+        }
+        const double etotnew = U / et + 0.5 * p.mvv2e * sum_mv2() / et;
+        crit = etotnew - etot;
+        const bool acc = metropolis(crit, S_ACC, m, 0);
+        if (acc) na += 1.0;
+        else { restore(true); wrap(); U = U0; W = W0; }
+        return acc;
+    }
+};
+
+// one workgroup = one replica for MOD moves
+template <class C>
+__global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int slot = blockIdx.x;
+    const int buf = p.slot2buf[slot];
+    const int tid = threadIdx.x;
+    Replica<C> R(p, smem, slot);
+    const int N = p.N;
+
+    R.load(buf);
+    if (p.eval_only) { // nm_eval: batched lj_energy_force on the resident states
+        R.L = p.box[buf];
+        R.wrap();
+        R.eval(true);
+        if (tid == 0) {
+            p.evalU[slot] = R.U; p.evalW[slot] = R.W; p.status[slot] |= R.status;
+            double *st = p.stats + 4 * (size_t)slot;
+            st[0] += R.st_evals; st[1] += R.st_rebuilds; st[2] += R.st_eevals; st[3] += R.st_pairs;
+        }
+        if (p.evalF)
+            for (int a = tid; a < 3 * N; a += C::BLOCK) {
+                const int i = a / 3, c = a - 3 * i;
+                p.evalF[(size_t)slot * 3 * N + a] = (c == 0 ? R.fx : c == 1 ? R.fy : R.fz)[i];
+            }
+        return;
+    }
+
+    // init_lammps (remcmc:459-470): change_box %f, scatter x, v, run 0
+    R.L = q6(p.box[buf]);
+    R.setup();
+
+    const double et = p.et[slot], pf = p.pf[slot], t = p.tq[slot];
+    const double dx = p.steps[3 * buf], dv = p.steps[3 * buf + 1], dt = p.steps[3 * buf + 2];
+    double ntp = p.count[6 * slot], nap = p.count[6 * slot + 1], ntv = p.count[6 * slot + 2];
+    double nav = p.count[6 * slot + 3], nth = p.count[6 * slot + 4], nah = p.count[6 * slot + 5];
+    const int fatal = ST_BOX_TOO_SMALL | ST_LIST_OVERFLOW;
+
+    for (int m = 0; m < p.mod && !(R.status & fatal); ++m) {
+        const double roll = R.draw_scalar(S_ROLL, (uint32_t)m, 0); // move_mc, remcmc:645
+        double crit = 0.0, branch;
+        int acc;
+        if (roll <= p.ppos) {
+            if (p.bulk) { branch = 0.0; acc = R.bulk_pmc((uint32_t)m, et, dx, ntp, nap, crit); }
+            else { branch = 3.0; acc = R.iter_pmc((uint32_t)m, et, dx, ntp, nap, crit); }
+        } else if (roll <= p.ppos + p.pvol) {
+            branch = 1.0; acc = R.vmc((uint32_t)m, et, pf, dv, ntv, nav, crit);
+        } else {
+            branch = 2.0; acc = R.hmc((uint32_t)m, et, t, dt, nth, nah, crit);
+        }
+        if (p.trace && tid == 0) {
+            double *tr = p.trace + ((size_t)slot * p.mod + m) * 4;
+            tr[0] = branch; tr[1] = (double)acc; tr[2] = crit; tr[3] = R.U;
+        }
+    }
+
+    // lammps_extract (remcmc:377-391) and the acceptance ratios (remcmc:685-688)
+    const double smv2 = R.sum_mv2();
+    R.store(buf);
+    if (tid == 0) {
+        const double dof = 3.0 * N - 3.0;
+        const double temp = smv2 * p.mvv2e / (dof * p.kB);
+        const double vol3 = R.L * R.L * R.L;
+        double *th = p.therm + 5 * (size_t)buf;
+        th[0] = temp;
+        th[1] = R.U;
+        th[2] = 0.5 * p.mvv2e * smv2;
+        th[3] = (dof * p.kB * temp + R.W) / 3.0 * (1.0 / vol3) * p.nktv2p;
+        th[4] = pow(R.L, 3.0);
+        p.box[buf] = R.L;
+        double *c = p.count + 6 * (size_t)slot;
+        c[0] = ntp; c[1] = nap; c[2] = ntv; c[3] = nav; c[4] = nth; c[5] = nah;
+        float *r = p.ratio + 3 * (size_t)slot;
+        r[0] = (ntp > 0.0) ? (float)nap / (float)ntp : 0.0f;
+        r[1] = (ntv > 0.0) ? (float)nav / (float)ntv : 0.0f;
+        r[2] = (nth > 0.0) ? (float)nah / (float)nth : 0.0f;
+        if (R.tape && R.tpos > R.tlen) R.status |= ST_TAPE_EXHAUSTED;
+        p.status[slot] |= R.status;
+        double *st = p.stats + 4 * (size_t)slot;
+        st[0] += R.st_evals; st[1] += R.st_rebuilds; st[2] += R.st_eevals; st[3] += R.st_pairs;
+    }
+}
+
+// gen_mc_param (remcmc:726-745): one thread per slot
+__global__ void nm_adapt_kernel(int nslots, const int *slot2buf, double *steps, double *count, float *ratio)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nslots) return;
+    const int b = slot2buf[k];
+    for (int c = 0; c < 3; ++c) {
+        const float a = ratio[3 * k + c];
+        double s = steps[3 * b + c];
+        if (a < 0.5f) s = 0.9375 * s;
+        if (a > 0.5f) s = 1.0625 * s;
+        steps[3 * b + c] = s;
+        ratio[3 * k + c] = 0.0f;
+    }
+    for (int c = 0; c < 6; ++c) count[6 * k + c] = 0.0;
+}
+
+// replica_exchange (remcmc:776-803): rows are independent, the sweep inside a row is strictly sequential.
+// A swap exchanges entries [0..11] of the two state lists = configuration, thermo scalars and dx,dv,dt; here
+// that is one swap of slot->buffer labels, no coordinate moves.
+__global__ void nm_exchange_kernel(int nrows, int nt, int row0, uint32_t seed, uint32_t step, int *slot2buf,
+                                   const double *therm, const double *et, const double *pf, const double *tape,
+                                   double *crit_out, int *nswaps)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const int ppr = nt * (nt - 1) / 2;
+    int q = 0, sw = 0;
+    for (int vv = nt - 1; vv >= 0; --vv)
+        for (int w = 0; w < vv; ++w, ++q) {
+            const int i = r * nt + vv, j = r * nt + w;
+            const int bi = slot2buf[i], bj = slot2buf[j];
+            const double de = (therm[5 * bi + 1] + therm[5 * bi + 2]) - (therm[5 * bj + 1] + therm[5 * bj + 2]);
+            const double dvol = therm[5 * bi + 4] - therm[5 * bj + 4];
+            const double dh = de * (1.0 / et[i] - 1.0 / et[j]) + (pf[i] - pf[j]) * dvol;
+            double u;
+            if (tape) u = tape[r * ppr + q];
+            else {
+                uint32_t o[4];
+                philox4x32_10((uint32_t)((row0 + r) * ppr + q), S_EXCH, 0u, step, seed, 0xFFFFFFFFu, o);
+                u = u01(o[0], o[1]);
+            }
+            if (crit_out) crit_out[r * ppr + q] = dh;
+            const double e = exp(dh);
+            const double mm = (e != e) ? e : (e < 1.0 ? e : 1.0);
+            if (u <= mm) { slot2buf[i] = bj; slot2buf[j] = bi; ++sw; }
+        }
+    if (sw) atomicAdd(nswaps, sw);
+}
+
+} // namespace nm

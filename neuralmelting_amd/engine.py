@@ -1,0 +1,192 @@
+"""Engine — Python face of the C-ABI (include/nm.h): one context per GPU holding a contiguous range of
+pressure rows of the P x T replica grid.  Mirrors the per-replica functions the reference's orchestration
+maps over: gen_samples -> run_block, gen_mc_params -> adapt, replica_exchange -> exchange."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as B
+
+
+class NMError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, 'nm error %d: %s' % (code, msg))
+        self.code = code
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(B.c_double_p)
+
+
+class Engine:
+    """batched replica engine on one MI355X"""
+
+    ELEMENTS = {'LJ': B.NM_EL_LJ, 'Al': B.NM_EL_AL}
+
+    def __init__(self, natoms, P, T, *, element='LJ', ppos=0.125, pvol=0.125, nstps=8, bulk=True, seed=256,
+                 device=0, row0=0, nrows=None, iter_revert=False):
+        self.lib = B.load()
+        self._P = np.ascontiguousarray(P, dtype=np.float32)
+        self._T = np.ascontiguousarray(T, dtype=np.float32)
+        self.np, self.nt = len(self._P), len(self._T)
+        self.row0 = int(row0)
+        self.nrows = self.np - self.row0 if nrows is None else int(nrows)
+        cfg = B.NMConfig()
+        cfg.size = C.sizeof(B.NMConfig)
+        cfg.element = self.ELEMENTS[element]
+        cfg.natoms = int(natoms)
+        cfg.np, cfg.nt, cfg.row0, cfg.nrows = self.np, self.nt, self.row0, self.nrows
+        cfg.nstps, cfg.bulk, cfg.iter_revert = int(nstps), int(bool(bulk)), int(bool(iter_revert))
+        cfg.device, cfg.seed = int(device), int(seed)
+        cfg.ppos, cfg.pvol = float(ppos), float(pvol)
+        cfg.P = self._P.ctypes.data_as(B.c_float_p)
+        cfg.T = self._T.ctypes.data_as(B.c_float_p)
+        h = C.c_void_p()
+        rc = self.lib.nm_create(C.byref(cfg), C.byref(h))
+        if rc != B.NM_OK:
+            raise NMError(rc, self.lib.nm_last_error(None).decode())
+        self.h = h
+        self.natoms = int(natoms)
+        self.nslots = self.lib.nm_nslots(self.h)
+
+    # -- plumbing
+    def _chk(self, rc):
+        if rc != B.NM_OK:
+            raise NMError(rc, self.lib.nm_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.nm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- constants / state
+    def constants(self):
+        """(et, pf) per local slot: init_constants, remcmc:114-141"""
+        et, pf = np.empty(self.nslots), np.empty(self.nslots)
+        self._chk(self.lib.nm_get_const(self.h, _dp(et), _dp(pf)))
+        return et, pf
+
+    def set_state(self, x=None, v=None, box=None, dxdvdt=None, k0=0, nk=None):
+        nk = self.nslots - k0 if nk is None else nk
+        n3 = 3 * self.natoms
+
+        def prep(a, shape):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            if a.size != int(np.prod(shape)):
+                raise ValueError('bad array size %d, expected %s' % (a.size, shape))
+            return a
+        x, v, box, dxdvdt = prep(x, (nk, n3)), prep(v, (nk, n3)), prep(box, (nk,)), prep(dxdvdt, (nk, 3))
+        self._chk(self.lib.nm_set_state(self.h, k0, nk, _dp(x), _dp(v), _dp(box), _dp(dxdvdt)))
+
+    def get_state(self, k0=0, nk=None):
+        nk = self.nslots - k0 if nk is None else nk
+        n3 = 3 * self.natoms
+        x, v = np.empty((nk, n3)), np.empty((nk, n3))
+        box, d = np.empty(nk), np.empty((nk, 3))
+        self._chk(self.lib.nm_get_state(self.h, k0, nk, _dp(x), _dp(v), _dp(box), _dp(d)))
+        return x, v, box, d
+
+    def set_step(self, step):
+        self._chk(self.lib.nm_set_step(self.h, int(step)))
+
+    # -- the hot path
+    def run_block(self, mod):
+        """gen_samples (remcmc:694-719): MOD moves for every replica, asynchronous"""
+        self._chk(self.lib.nm_run_block(self.h, int(mod)))
+
+    def thermo(self):
+        """rows[nslots][17] in the .thrm column order (remcmc:208)"""
+        rows = np.empty((self.nslots, B.NM_THERMO_COLS))
+        self._chk(self.lib.nm_get_thermo(self.h, _dp(rows)))
+        return rows
+
+    def adapt(self):
+        """gen_mc_params (remcmc:748-770)"""
+        self._chk(self.lib.nm_adapt(self.h))
+
+    def exchange(self, count=True):
+        """replica_exchange (remcmc:776-803); returns the number of swaps when count=True"""
+        if not count:
+            self._chk(self.lib.nm_exchange(self.h, None))
+            return None
+        n = C.c_int(0)
+        self._chk(self.lib.nm_exchange(self.h, C.byref(n)))
+        return n.value
+
+    def synchronize(self):
+        self._chk(self.lib.nm_synchronize(self.h))
+
+    # -- measurement
+    def timing_reset(self):
+        self._chk(self.lib.nm_timing_reset(self.h))
+
+    def timing(self):
+        """(launches, total_ms) of the run_block kernel, from HIP events on the engine's stream"""
+        n, ms = C.c_int(0), C.c_double(0.0)
+        self._chk(self.lib.nm_timing_get(self.h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def stats(self, reset=False):
+        """per-slot (evaluations, list rebuilds, energy evaluations, interacting pairs summed over those)"""
+        s = np.empty((self.nslots, B.NM_STATS_COLS))
+        self._chk(self.lib.nm_stats_get(self.h, _dp(s), int(reset)))
+        return s
+
+    # -- test-only
+    def eval(self, forces=True):
+        U, W = np.empty(self.nslots), np.empty(self.nslots)
+        f = np.empty((self.nslots, 3 * self.natoms)) if forces else None
+        self._chk(self.lib.nm_eval(self.h, _dp(U), _dp(W), _dp(f)))
+        return U, W, f
+
+    def set_rng_tape(self, tapes):
+        """tapes: list of 1-D arrays (one per slot) or None"""
+        if tapes is None:
+            self._chk(self.lib.nm_set_rng_tape(self.h, None, None))
+            return
+        off = np.zeros(self.nslots + 1, dtype=np.int32)
+        off[1:] = np.cumsum([len(t) for t in tapes])
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.float64) for t in tapes]))
+        if flat.size == 0:
+            flat = np.zeros(1)
+        self._chk(self.lib.nm_set_rng_tape(self.h, _dp(flat), off.ctypes.data_as(B.c_int_p)))
+
+    def set_exchange_tape(self, tape):
+        if tape is None:
+            self._chk(self.lib.nm_set_exchange_tape(self.h, None, 0))
+            return
+        t = np.ascontiguousarray(tape, dtype=np.float64)
+        self._chk(self.lib.nm_set_exchange_tape(self.h, _dp(t), len(t)))
+
+    def set_trace(self, on):
+        self._chk(self.lib.nm_set_trace(self.h, int(bool(on))))
+
+    def trace(self, mod):
+        tr = np.empty((self.nslots, mod, B.NM_TRACE_COLS))
+        self._chk(self.lib.nm_get_trace(self.h, _dp(tr), int(mod)))
+        return tr
+
+    def perm(self):
+        p = np.empty(self.nslots, dtype=np.int32)
+        self._chk(self.lib.nm_get_perm(self.h, p.ctypes.data_as(B.c_int_p)))
+        return p
+
+    def exchange_crit(self):
+        n = self.nrows * self.nt * (self.nt - 1) // 2
+        c = np.empty(max(n, 1))
+        self._chk(self.lib.nm_get_exchange_crit(self.h, _dp(c), n))
+        return c[:n]

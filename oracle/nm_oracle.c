@@ -510,7 +510,7 @@ static uint32_t draw_tag(drawctx *d, uint32_t m)
 {
     if (d->p->tape) { /* np.random.randint(1, 2**16) site: remcmc:482, 603 */
         if (d->pos >= d->p->tape_len) { d->pos++; return 0; }
-        return (uint32_t)d->p->tape[d->pos++];
+        return (uint32_t)(d->p->tape[d->pos++] * 65536.0); /* tape stores randint/65536 */
     }
     return m;
 }
@@ -580,6 +580,8 @@ int orc_run_block(orc_sim *s, const orc_block_params *p, double *x, double *v, d
                iter_revert = 1 is the corrected move. */
             branch = 3;
             double boxl = orc_get_box(s);
+            wrap_all(s); /* one consistent remap at move start (deviation: the reference re-sends stale
+                            out-of-box coordinates on every trial, inflating LAMMPS image flags) */
             orc_get_x(s, xs);
             for (int k = 0; k < n; ++k) {
                 ntp += 1;

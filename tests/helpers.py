@@ -1,0 +1,68 @@
+"""shared helpers of the parity tests: the reference's main loop (remcmc:977-995) driven on the oracle"""
+import numpy as np
+
+from neuralmelting_amd import lattice
+
+LAT_LJ = 1.122
+
+
+def grids(npn, ntn, pr=(1.0, 8.0), tr=(0.25, 2.5)):
+    """P, T float32 grids, remcmc:895-897"""
+    return np.linspace(pr[0], pr[1], npn, dtype=np.float32), np.linspace(tr[0], tr[1], ntn, dtype=np.float32)
+
+
+def constants_lj(P, T, row0=0, nrows=None):
+    """init_constant for lj units in float64 on the float32 grid values (remcmc:128-131)"""
+    nrows = len(P) - row0 if nrows is None else nrows
+    et = np.array([float(T[j]) for r in range(nrows) for j in range(len(T))])
+    pf = np.array([float(P[row0 + r]) / float(T[j]) for r in range(nrows) for j in range(len(T))])
+    tq = et.copy()
+    return et, pf, tq
+
+
+class OracleLoop:
+    """gen_samples / gen_mc_params / replica_exchange on the oracle, holding STATE like the reference does"""
+
+    def __init__(self, O, sz, P, T, *, dx=0.03125, dv=0.03125, ppos=0.125, pvol=0.125, nstps=8, bulk=True, seed=256,
+                 row0=0, nrows=None, iter_revert=False, nthreads=0):
+        self.O = O
+        self.P, self.T = P, T
+        self.nt = len(T)
+        self.row0 = row0
+        self.nrows = len(P) - row0 if nrows is None else nrows
+        self.ns = self.nrows * self.nt
+        self.natoms = 4 * sz ** 3
+        self.kw = dict(natoms=self.natoms, nstps=nstps, bulk=bulk, ppos=ppos, pvol=pvol, lat=LAT_LJ, seed=seed,
+                       iter_revert=iter_revert, nthreads=nthreads)
+        self.seed = seed
+        self.x, self.v, self.box, self.d = lattice.init_states(sz, P, T, dx, dv, seed=seed, row0=row0, nrows=self.nrows)
+        self.et, self.pf, self.tq = constants_lj(P, T, row0, self.nrows)
+        self.thermo = np.zeros((self.ns, 5))
+        self.thermo[:, 4] = self.box ** 3
+        self.counters = np.zeros((self.ns, 6))
+        self.ratios = np.zeros((self.ns, 3), dtype=np.float32)
+
+    def run_block(self, mod, step):
+        out = self.O.run_blocks(self.x, self.v, self.box, self.d, self.tq, self.et, self.pf, mod=mod,
+                                slot0=self.row0 * self.nt, step=step, **self.kw)
+        self.x, self.v, self.box = out['x'], out['v'], out['box']
+        self.thermo, self.counters, self.ratios = out['thermo'], out['counters'], out['ratios']
+
+    def rows(self):
+        """the 17 .thrm columns (remcmc:235-245)"""
+        return np.concatenate([self.thermo[:, :5], self.d, self.counters, self.ratios.astype(np.float64)], axis=1)
+
+    def adapt(self):
+        for k in range(self.ns):
+            self.d[k] = self.O.adapt(self.ratios[k], self.d[k])
+        self.counters[:] = 0
+        self.ratios[:] = 0
+
+    def exchange(self, step, tape=None):
+        etot = self.thermo[:, 1] + self.thermo[:, 2]
+        swaps, perm, _, _, crit = self.O.exchange(len(self.P), self.nt, self.row0, self.nrows, self.seed, step, etot,
+                                                  self.thermo[:, 4], self.et, self.pf, tape=tape)
+        # entries [0..11] travel: configuration, thermo scalars, dx dv dt (remcmc:798)
+        self.x, self.v, self.box = self.x[perm], self.v[perm], self.box[perm]
+        self.thermo, self.d = self.thermo[perm], self.d[perm]
+        return swaps, perm, crit

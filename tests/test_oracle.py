@@ -1,0 +1,122 @@
+"""CPU tests: pin the oracle itself (known answers, Philox vectors, '%f' round trip, list vs direct sum)."""
+import numpy as np
+import pytest
+
+from neuralmelting_amd import lattice
+
+
+def perfect(sz):
+    a = lattice.lattice_constant('LJ')
+    return lattice.fcc_fractional(sz) * (sz * a), sz * a
+
+
+def test_philox_known_answers(oracle):
+    # Random123 kat_vectors, philox4x32-10
+    assert oracle.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert oracle.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert oracle.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_q6_matches_printf(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(7)
+    vals = np.concatenate([rng.uniform(0, 13, 50000), rng.uniform(0, 0.05, 20000),
+                           [1 / 128, 0.00390625, 0.5714285969734192, 2.5e-7, 1.5e-6, 0.0, 6.0303160521]])
+    for v in vals:
+        assert L.orc_q6(v) == L.orc_q6_printf(v), repr(v)
+    assert '%f' % 0.00390625 == '0.003906' and L.orc_q6(0.00390625) == 0.003906
+    assert L.orc_q6(float(np.float32(0.5714286))) == 0.571429
+
+
+@pytest.mark.parametrize('sz,pairs,U', [(4, 9984, -2056.929100246), (6, 33696, -6942.135713329)])
+def test_fcc_known_answer(oracle, sz, pairs, U):
+    # perfect fcc LJ at rho*=1.122, rc=2.5 unshifted
+    x, box = perfect(sz)
+    n = len(x)
+    s = oracle.Sim(n)
+    s.set_box(box); s.set_x(x.ravel()); s.set_v(np.zeros(3 * n)); s.setup()
+    assert s.npairs == pairs
+    assert abs(s.pe / n - (-8.034879297835)) < 1e-10
+    assert abs(s.pe - U) < 1e-6
+    assert abs(s.press - 3.540508884) < 1e-8
+    assert np.abs(s.get_f()).max() < 1e-10
+
+
+def test_relaxed_boxes():
+    for P, L in [(0, 6.198413696), (1, 6.170385810), (2, 6.145160290), (4, 6.101094662), (8, 6.030316052)]:
+        assert abs(lattice.relax_box(4, P) - L) < 2e-9
+
+
+def test_list_matches_direct_sum(oracle):
+    x, box = perfect(4)
+    rng = np.random.default_rng(3)
+    n = len(x)
+    s = oracle.Sim(n)
+    for amp in (0.05, 0.2, 0.5):
+        xx = x + amp * (rng.random(x.shape) - 0.5)
+        s.set_box(box); s.set_x(xx.ravel()); s.setup()
+        U, W, f = s.eval_allpairs()
+        assert abs(U - s.pe) <= 1e-11 * abs(U)
+        assert abs(W - s.virial) <= 1e-11 * abs(W)
+        np.testing.assert_allclose(s.get_f(), f, rtol=0, atol=1e-9 * np.abs(f).max())
+
+
+def test_velocity_create_exact_temperature(oracle):
+    x, box = perfect(4)
+    n = len(x)
+    s = oracle.Sim(n)
+    s.set_rng(256, 3, 0)
+    s.set_box(box); s.set_x(x.ravel()); s.setup()
+    s.velocity_create(0.571429, 12345)
+    assert abs(s.temp - 0.571429) < 1e-12          # rescaled to exactly t with dof = 3N-3
+    v = s.get_v().reshape(-1, 3)
+    assert np.abs(v.sum(0)).max() < 1e-12          # COM momentum removed
+    s.zero_angular()
+    v = s.get_v().reshape(-1, 3)
+    r = s.get_x().reshape(-1, 3)
+    r = r - r.mean(0)
+    assert np.abs(np.cross(r, v).sum(0)).max() < 1e-10
+    assert s.temp < 0.571429                        # not re-scaled afterwards
+
+
+def test_verlet_second_order(oracle):
+    # velocity-Verlet (fix nve): global position error after a fixed time scales as h^2.  (The total energy is not a
+    # usable probe: the unshifted cutoff makes U jump by 0.0163 whenever a pair crosses rc.)
+    x, box = perfect(4)
+    n = len(x)
+    rng = np.random.default_rng(5)
+    xx = (x + 0.05 * (rng.random(x.shape) - 0.5)).ravel()
+    finals = []
+    for h, steps in ((0.004, 8), (0.002, 16), (0.001, 32), (0.00025, 128)):
+        s = oracle.Sim(n)
+        s.set_rng(1, 0, 0)
+        s.set_box(box); s.set_x(xx); s.setup()
+        s.velocity_create(1.0, 1)
+        s.set_timestep(h)
+        s.run(steps)
+        finals.append(s.get_x())
+    e = [np.abs(f - finals[-1]).max() for f in finals[:-1]]
+    assert 3.0 < e[0] / e[1] < 5.5 and 3.0 < e[1] / e[2] < 5.5
+
+
+def test_adapt_rule(oracle):
+    # gen_mc_param, remcmc:726-745
+    d = oracle.adapt(np.float32([0.0, 0.5, 1.0]), [1.0, 1.0, 1.0])
+    np.testing.assert_array_equal(d, [0.9375, 1.0, 1.0625])
+    d = oracle.adapt(np.float32([0.49, 0.51, 0.5]), [2.0, 2.0, 2.0])
+    np.testing.assert_array_equal(d, [1.875, 2.125, 2.0])
+
+
+def test_exchange_toy_detailed_balance(oracle):
+    # two slots of one row, identical volumes: accept prob = min(1, exp((E_i-E_j)(beta_i-beta_j)))
+    et = np.array([1.0, 2.0]); pf = np.array([1.0, 0.5])
+    etot = np.array([-3.0, -1.0]); vol = np.array([5.0, 5.0])
+    # i = hot slot (index 1), j = cold slot (0): dh = (E1-E0)(1/2-1) = -1 -> p = exp(-1)
+    acc = 0
+    n = 4000
+    for step in range(n):
+        swaps, perm, _, _, crit = oracle.exchange(1, 2, 0, 1, 99, step, etot, vol, et, pf)
+        assert abs(crit[0] + 1.0) < 1e-15
+        acc += swaps
+    assert abs(acc / n - np.exp(-1.0)) < 4 * np.sqrt(np.exp(-1) * (1 - np.exp(-1)) / n)

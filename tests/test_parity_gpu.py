@@ -1,0 +1,200 @@
+"""GPU parity tests: the HIP path (through the C-ABI, libnm_hip.so) against the CPU oracle on the same seeded
+inputs.  Tolerance: 1e-6 relative on energies / criteria (BASELINE.json north_star); decisions, counters,
+branches and exchange permutations must be identical."""
+import numpy as np
+import pytest
+
+from helpers import OracleLoop, grids
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6  # north_star tolerance for floating point
+
+
+def make_engine(loop, sz, P, T, **kw):
+    import neuralmelting_amd as nm
+    e = nm.Engine(4 * sz ** 3, P, T, row0=loop.row0, nrows=loop.nrows, seed=loop.seed, **kw)
+    e.set_state(loop.x, loop.v, loop.box, loop.d)
+    return e
+
+
+def test_library_is_the_hip_one():
+    import neuralmelting_amd._lib as B
+    L = B.load()
+    assert B.LIB_PATH.endswith('libnm_hip.so')
+    for s in B.SYMBOLS:
+        assert hasattr(L, s)
+
+
+@pytest.mark.parametrize('sz', [4, 6, 8])
+def test_eval_parity(oracle, sz):
+    """batched lj_energy_force (a-1) vs the oracle's list evaluation and direct sum"""
+    P, T = grids(2, 2)
+    loop = OracleLoop(oracle, sz, P, T)
+    e = make_engine(loop, sz, P, T)
+    U, W, f = e.eval()
+    n = loop.natoms
+    for k in range(loop.ns):
+        s = oracle.Sim(n)
+        s.set_box(loop.box[k]); s.set_x(loop.x[k]); s.setup()
+        assert abs(U[k] - s.pe) <= 1e-11 * abs(s.pe)
+        assert abs(W[k] - s.virial) <= 1e-10 * abs(s.virial)
+        fo = s.get_f()
+        np.testing.assert_allclose(f[k], fo, rtol=0, atol=1e-10 * np.abs(fo).max())
+    e.close()
+
+
+def test_eval_known_answer_fcc():
+    """SURVEY.md §8c known answers straight through the HIP path"""
+    import neuralmelting_amd as nm
+    from neuralmelting_amd import lattice
+    P, T = grids(1, 1)
+    for sz, pairs in ((4, 9984), (6, 33696), (8, 79872)):
+        box = sz * lattice.lattice_constant('LJ')
+        x = (lattice.fcc_fractional(sz) * box).reshape(1, -1)
+        n = 4 * sz ** 3
+        e = nm.Engine(n, P, T)
+        e.set_state(x, np.zeros_like(x), [box], [[0.03125, 0.03125, 0.00390625]])
+        U, W, f = e.eval()
+        assert abs(U[0] / n - (-8.034879297835)) < 1e-10
+        assert abs(W[0] / (3 * box ** 3) - 3.540508884) < 1e-8
+        assert np.abs(f).max() < 1e-9
+        st = e.stats()
+        assert st[0, 3] == pairs
+        e.close()
+
+
+@pytest.mark.parametrize('bulk', [True, False])
+def test_block_trace_parity(oracle, bulk):
+    """one block of moves, move by move: branch, decision, criterion, energy after (a-2..a-7)"""
+    sz, mod = 4, 24
+    P, T = grids(2, 2)
+    kw = dict(bulk=bulk, ppos=0.25, pvol=0.25)
+    loop = OracleLoop(oracle, sz, P, T, **kw)
+    e = make_engine(loop, sz, P, T, **kw)
+    e.set_trace(True)
+    e.set_step(0)
+    e.run_block(mod)
+    rows = e.thermo()
+    tr = e.trace(mod)
+    n = loop.natoms
+    for k in range(loop.ns):
+        s = oracle.Sim(n)
+        s.set_rng(loop.seed, loop.row0 * loop.nt + k, 0)
+        out = s.run_block(loop.x[k], loop.v[k], loop.box[k], loop.d[k], mod=mod, nstps=8, bulk=bulk, ppos=0.25, pvol=0.25,
+                          lat=1.122, t=loop.tq[k], et=loop.et[k], pf=loop.pf[k], trace=True)
+        to = out['trace']
+        np.testing.assert_array_equal(tr[k, :, 0], to[:, 0])           # branch
+        np.testing.assert_array_equal(tr[k, :, 1], to[:, 1])           # accepted
+        np.testing.assert_allclose(tr[k, :, 2], to[:, 2], rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(tr[k, :, 3], to[:, 3], rtol=RTOL)
+        np.testing.assert_allclose(rows[k, :5], out['thermo'], rtol=RTOL)
+        np.testing.assert_array_equal(rows[k, 8:14], out['counters'])
+        np.testing.assert_array_equal(rows[k, 14:17].astype(np.float32), out['ratios'])
+    x, v, box, d = e.get_state()
+    e.close()
+
+
+def test_cycles_parity_with_exchange(oracle):
+    """three full cycles of the main loop (remcmc:977-995): gen_samples, thermo rows, gen_mc_params, exchange"""
+    sz, mod, ncyc = 4, 16, 3
+    P, T = grids(2, 4)
+    loop = OracleLoop(oracle, sz, P, T)
+    e = make_engine(loop, sz, P, T)
+    for step in range(ncyc):
+        e.set_step(step)
+        e.run_block(mod)
+        rows = e.thermo()
+        loop.run_block(mod, step)
+        ro = loop.rows()
+        np.testing.assert_allclose(rows[:, :8], ro[:, :8], rtol=RTOL)
+        np.testing.assert_array_equal(rows[:, 8:], ro[:, 8:])
+        e.adapt()
+        loop.adapt()
+        nsw = e.exchange()
+        swaps, perm, crit = loop.exchange(step)
+        assert nsw == swaps
+        np.testing.assert_allclose(e.exchange_crit(), crit, rtol=RTOL, atol=1e-9)
+    x, v, box, d = e.get_state()
+    np.testing.assert_allclose(box, loop.box, rtol=1e-12)
+    np.testing.assert_array_equal(d, loop.d)
+    # configurations agree up to the accumulated round-off of different summation orders
+    np.testing.assert_allclose(x, loop.x, rtol=0, atol=1e-7)
+    e.close()
+
+
+def test_tape_replay_parity(oracle):
+    """externally supplied uniforms (the order of the reference's np.random calls) drive both paths identically"""
+    sz, mod = 4, 20
+    P, T = grids(1, 2)
+    loop = OracleLoop(oracle, sz, P, T)
+    rng = np.random.default_rng(11)
+    tapes = []
+    for k in range(loop.ns):
+        tapes.append(rng.random(4 * mod))  # tags are stored as randint/65536, so every entry is a uniform
+    e = make_engine(loop, sz, P, T)
+    e.set_rng_tape(tapes)
+    e.set_trace(True)
+    e.run_block(mod)
+    tr = e.trace(mod)
+    rows = e.thermo()
+    for k in range(loop.ns):
+        s = oracle.Sim(loop.natoms)
+        s.set_rng(loop.seed, k, 0)
+        out = s.run_block(loop.x[k], loop.v[k], loop.box[k], loop.d[k], mod=mod, nstps=8, bulk=True, ppos=0.125, pvol=0.125,
+                          lat=1.122, t=loop.tq[k], et=loop.et[k], pf=loop.pf[k], tape=tapes[k], trace=True)
+        np.testing.assert_array_equal(tr[k, :, :2], out['trace'][:, :2])
+        np.testing.assert_allclose(tr[k, :, 2:], out['trace'][:, 2:], rtol=RTOL, atol=1e-7)
+        np.testing.assert_array_equal(rows[k, 8:14], out['counters'])
+    e.close()
+
+
+@pytest.mark.parametrize('sz', [6, 8])
+def test_block_parity_large_cells(oracle, sz):
+    """the HBM-list kernels (6^3: 864 atoms, 8^3: 2048 atoms) against the oracle"""
+    mod = 6
+    P, T = grids(1, 2)
+    loop = OracleLoop(oracle, sz, P, T)
+    e = make_engine(loop, sz, P, T)
+    e.set_trace(True)
+    e.run_block(mod)
+    rows = e.thermo()
+    tr = e.trace(mod)
+    loop.run_block(mod, 0)
+    ro = loop.rows()
+    np.testing.assert_allclose(rows[:, :8], ro[:, :8], rtol=RTOL)
+    np.testing.assert_array_equal(rows[:, 8:], ro[:, 8:])
+    e.close()
+
+
+def test_sharded_rows_equal_single_context(oracle):
+    """rows [0,1) and [1,2) run in two contexts reproduce the single-context result bit for bit (RNG keyed by global slot)"""
+    sz, mod = 4, 8
+    P, T = grids(2, 2)
+    import neuralmelting_amd as nm
+    full = OracleLoop(oracle, sz, P, T)
+    e = make_engine(full, sz, P, T)
+    e.run_block(mod); e.adapt(); e.exchange(); e.set_step(1); e.run_block(mod)
+    ref = e.thermo()
+    e.close()
+    parts = []
+    for r in range(2):
+        lp = OracleLoop(oracle, sz, P, T, row0=r, nrows=1)
+        ee = make_engine(lp, sz, P, T)
+        ee.run_block(mod); ee.adapt(); ee.exchange(); ee.set_step(1); ee.run_block(mod)
+        parts.append(ee.thermo())
+        ee.close()
+    np.testing.assert_array_equal(np.concatenate(parts), ref)
+
+
+def test_failure_is_loud():
+    """a box below 2*rc is outside the minimum-image regime: the engine reports it instead of returning numbers"""
+    import neuralmelting_amd as nm
+    P, T = grids(1, 1)
+    n = 256
+    x = np.random.default_rng(0).random((1, 3 * n)) * 4.0
+    e = nm.Engine(n, P, T)
+    e.set_state(x, np.zeros_like(x), [4.0], [[0.03, 0.03, 0.004]])
+    with pytest.raises(nm.NMError):
+        e.eval()
+    e.close()
