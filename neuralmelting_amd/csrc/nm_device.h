@@ -68,10 +68,13 @@ __device__ __forceinline__ double u01(uint32_t hi, uint32_t lo)
 // amplitude to LAMMPS through '%f' strings (remcmc:466,483,571,604,607)
 __device__ __forceinline__ double q6(double x)
 {
+    // the product and the difference must be individually rounded: hipcc's default fp-contract=fast would fuse
+    // p - n into fma(x, 1e6, -n) and lose the tie test (0.03125*1.122 -> 35062.5 is such a tie)
+#pragma clang fp contract(off)
     const double p = x * 1.0e6;
     double n = rint(p);
     if (fabs(p - n) == 0.5) {
-        const double e = fma(x, 1.0e6, -p);
+        const double e = __builtin_fma(x, 1.0e6, -p); // exact residual of the product
         if (e > 0.0) n = floor(p) + 1.0;
         else if (e < 0.0) n = floor(p);
     }

@@ -94,7 +94,7 @@ static void rng4(const orc_sim *s, uint32_t index, uint32_t stream, uint32_t tag
 }
 
 /* ------------------------------------------------------------------ '%f' round trip */
-double orc_q6(double x)
+__attribute__((optimize("fp-contract=off"))) double orc_q6(double x)
 {
     /* value of float('%f' % x): nearest double to the 6-decimal correctly rounded decimal of x */
     double p = x * 1.0e6;
