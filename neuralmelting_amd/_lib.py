@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnm_hip.so')
+LIB_PATH = os.environ.get('NM_HIP_LIB') or os.path.join(_HERE, 'libnm_hip.so')  # NM_HIP_LIB: dev override (diagnostic builds)
 
 c_double_p = C.POINTER(C.c_double)
 c_float_p = C.POINTER(C.c_float)

@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -14,9 +15,13 @@ using namespace nm;
 
 namespace {
 
-typedef Cfg<1024, 4, unsigned char, true, true> CfgSmall;    // N <= 256: everything incl. the byte list in LDS
-typedef Cfg<1024, 1, unsigned short, false, true> CfgMid;    // N <= 864: list in HBM/L2, saved copies in LDS
-typedef Cfg<1024, 1, unsigned short, false, false> CfgLarge; // N <= 2048: saved copies spill to HBM as well
+#ifndef NM_SMALL_BLOCK
+#define NM_SMALL_BLOCK 512 // 8 waves: 256 VGPRs per lane, no spills (1024 threads cap at 128 and spilled ~200)
+#define NM_SMALL_TPA 2
+#endif
+typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 160, unsigned char, true, true> CfgSmall;     // N <= 256: everything incl. the byte list in LDS
+typedef Cfg<512, 1, 864, 160, unsigned short, false, true> CfgMid;     // N <= 864: list in HBM/L2, saved copies in LDS
+typedef Cfg<512, 1, 2048, 160, unsigned short, false, false> CfgLarge; // N <= 2048: saved copies spill to HBM as well
 
 thread_local std::string g_create_error;
 
@@ -27,9 +32,8 @@ struct EvPair { hipEvent_t a, b; bool used; };
 struct nm_ctx {
     nm_config cfg;
     int N, nslots, slot0, kind; // kind: 0 small, 1 mid, 2 large
-    int maxnb;
     size_t lds_bytes, aux_doubles;
-    double lat, mass, kB, mvv2e, ftm2v, nktv2p;
+    double lat, mass, kB, mvv2e, ftm2v, nktv2p, skin;
     uint32_t step;
     hipStream_t stream;
     // device
@@ -39,6 +43,7 @@ struct nm_ctx {
     double *d_tape, *d_xtape, *d_trace, *d_xcrit, *d_evalU, *d_evalW, *d_evalF, *d_aux;
     int *d_tape_off;
     void *d_nbr;
+    unsigned long long *d_prof; // diagnostic build only (NM_PROF)
     size_t trace_cap;
     int trace_on, trace_mod;
     int xtape_n;
@@ -73,17 +78,17 @@ void fill_params(const nm_ctx *c, KParams &p)
     std::memset(&p, 0, sizeof p);
     p.N = c->N; p.nslots = c->nslots; p.slot0 = c->slot0;
     p.nstps = c->cfg.nstps; p.bulk = c->cfg.bulk; p.iter_revert = c->cfg.iter_revert;
-    p.maxnb = c->maxnb;
     p.seed = c->cfg.seed; p.step = c->step;
     p.ppos = c->cfg.ppos; p.pvol = c->cfg.pvol; p.lat = c->lat; p.mass = c->mass;
     p.kB = c->kB; p.mvv2e = c->mvv2e; p.ftm2v = c->ftm2v; p.nktv2p = c->nktv2p;
-    p.rc = 2.5; p.skin = 0.3;
+    p.rc = 2.5; p.skin = c->skin;
     p.x = c->d_x; p.v = c->d_v; p.box = c->d_box; p.steps = c->d_steps; p.therm = c->d_therm;
     p.count = c->d_count; p.ratio = c->d_ratio; p.slot2buf = c->d_slot2buf;
     p.et = c->d_et; p.pf = c->d_pf; p.tq = c->d_tq;
     p.status = c->d_status; p.stats = c->d_stats;
     p.tape = c->d_tape; p.tape_off = c->d_tape_off;
     p.nbr_g = c->d_nbr; p.aux_g = c->d_aux;
+    p.prof = c->d_prof;
 }
 
 template <class C>
@@ -167,6 +172,8 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     c->trace_on = 0; c->trace_mod = 0; c->trace_cap = 0; c->xtape_n = 0;
     c->ev_next = 0; c->launches = 0; c->total_ms = 0.0;
     // material tables, remcmc:873-893
+    c->skin = 0.3; // Verlet-list skin: not observable in results, only in the rebuild rate
+    if (const char *e = std::getenv("NM_SKIN")) { const double v = std::atof(e); if (v > 0.0 && v < 1.0) c->skin = v; }
     c->lat = 1.122; c->mass = 1.0; c->kB = 1.0; c->mvv2e = 1.0; c->ftm2v = 1.0; c->nktv2p = 1.0;
 
     // init_constant (remcmc:114-132) in float64 on the float32-rounded grid values (NumPy-1.x promotion)
@@ -180,13 +187,10 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
         c->h_tq[k] = Tj;
     }
 
-    if (c->N <= 256) { c->kind = 0; c->maxnb = 160; }
-    else if (c->N <= 864) { c->kind = 1; c->maxnb = 160; }
-    else { c->kind = 2; c->maxnb = 160; }
-    Layout lay = c->kind == 0 ? make_layout<CfgSmall>(c->N, c->maxnb)
-               : c->kind == 1 ? make_layout<CfgMid>(c->N, c->maxnb) : make_layout<CfgLarge>(c->N, c->maxnb);
-    c->lds_bytes = lay.total;
-    c->aux_doubles = lay.aux_doubles;
+    size_t nbr_elems;
+    if (c->N <= CfgSmall::NMAX) { c->kind = 0; c->lds_bytes = CfgSmall::LDS_BYTES; c->aux_doubles = CfgSmall::AUX_DOUBLES; nbr_elems = CfgSmall::NBR_G_ELEMS; }
+    else if (c->N <= CfgMid::NMAX) { c->kind = 1; c->lds_bytes = CfgMid::LDS_BYTES; c->aux_doubles = CfgMid::AUX_DOUBLES; nbr_elems = CfgMid::NBR_G_ELEMS; }
+    else { c->kind = 2; c->lds_bytes = CfgLarge::LDS_BYTES; c->aux_doubles = CfgLarge::AUX_DOUBLES; nbr_elems = CfgLarge::NBR_G_ELEMS; }
 
 #define CHK(call)                                                                                     \
     do {                                                                                              \
@@ -209,8 +213,12 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     CHK(dalloc(&c->d_evalU, ns)); CHK(dalloc(&c->d_evalW, ns)); CHK(dalloc(&c->d_evalF, ns * n3));
     const int npairs = cfg->nrows * cfg->nt * (cfg->nt - 1) / 2;
     CHK(dalloc(&c->d_xcrit, (size_t)npairs)); CHK(dalloc(&c->d_xtape, (size_t)npairs));
+    c->d_prof = nullptr;
+#ifdef NM_PROF
+    CHK(dalloc(&c->d_prof, ns * 16)); CHK(hipMemset(c->d_prof, 0, ns * 16 * sizeof(unsigned long long)));
+#endif
     c->d_tape = nullptr; c->d_tape_off = nullptr; c->d_trace = nullptr; c->d_nbr = nullptr; c->d_aux = nullptr;
-    if (c->kind != 0) CHK(hipMalloc(&c->d_nbr, ns * (size_t)c->maxnb * c->N * sizeof(unsigned short)));
+    if (nbr_elems) CHK(hipMalloc(&c->d_nbr, ns * nbr_elems * sizeof(unsigned short)));
     if (c->aux_doubles) CHK(dalloc(&c->d_aux, ns * c->aux_doubles));
     CHK(hipMemset(c->d_x, 0, ns * n3 * sizeof(double))); CHK(hipMemset(c->d_v, 0, ns * n3 * sizeof(double)));
     CHK(hipMemset(c->d_box, 0, ns * sizeof(double))); CHK(hipMemset(c->d_steps, 0, ns * 3 * sizeof(double)));
@@ -242,7 +250,7 @@ int nm_destroy(nm_ctx *c)
     for (auto &e : c->ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     void *ptrs[] = { c->d_x, c->d_v, c->d_box, c->d_steps, c->d_therm, c->d_count, c->d_ratio, c->d_et, c->d_pf, c->d_tq,
                      c->d_stats, c->d_slot2buf, c->d_status, c->d_nswaps, c->d_evalU, c->d_evalW, c->d_evalF, c->d_xcrit,
-                     c->d_xtape, c->d_tape, c->d_tape_off, c->d_trace, c->d_nbr, c->d_aux };
+                     c->d_xtape, c->d_tape, c->d_tape_off, c->d_trace, c->d_nbr, c->d_aux, c->d_prof };
     for (void *q : ptrs) if (q) hipFree(q);
     hipStreamDestroy(c->stream);
     delete c;
@@ -427,6 +435,18 @@ int nm_stats_get(nm_ctx *c, double *stats, int reset)
     if (reset) HIPCHK(c, hipMemset(c->d_stats, 0, n * sizeof(double)));
     return NM_OK;
 }
+
+#ifdef NM_PROF
+// diagnostic build only: cycle sums per section and slot, [nslots][16]
+int nm_prof_get(nm_ctx *c, unsigned long long *out, int reset)
+{
+    if (!c || !out) return NM_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->d_prof, (size_t)c->nslots * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(c, hipMemset(c->d_prof, 0, (size_t)c->nslots * 16 * sizeof(unsigned long long)));
+    return NM_OK;
+}
+#endif
 
 int nm_eval(nm_ctx *c, double *U, double *W, double *f)
 {

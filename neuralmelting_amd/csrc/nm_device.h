@@ -21,7 +21,6 @@ struct KParams {
     int N, nslots, slot0;          // atoms, local replicas, global index of local slot 0
     int mod, nstps, bulk, iter_revert;
     int eval_only;                 // nm_eval: evaluate the loaded states and leave
-    int maxnb;                     // neighbour slots per atom
     uint32_t seed, step;
     double ppos, pvol, lat, mass;
     double kB, mvv2e, ftm2v, nktv2p;
@@ -41,6 +40,7 @@ struct KParams {
     double *evalU, *evalW, *evalF; // nm_eval outputs
     void *nbr_g;                   // global neighbour lists (N > 256): [slot][maxnb*N] uint16
     double *aux_g;                 // global spill of the saved copies (large N): [slot][AUX_DOUBLES(N)]
+    unsigned long long *prof;      // diagnostic build only
 };
 
 // ------------------------------------------------------------------------------------------ Philox4x32-10
@@ -81,6 +81,16 @@ __device__ __forceinline__ double q6(double x)
     return n / 1.0e6;
 }
 
+// A value every lane holds identically, moved to scalar registers: tells the compiler it is wave-uniform so it
+// stops occupying a VGPR pair (the block-wide sums and everything derived from them are such values).
+__device__ __forceinline__ double uniform(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // ------------------------------------------------------------------------------------------ reductions
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -107,7 +117,7 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red, int &par
     for (int q = 0; q < NV; ++q) {
         double s = 0.0;
         for (int w = 0; w < NW; ++w) s += r[w * NVMAX + q];
-        v[q] = s;
+        v[q] = uniform(s);
     }
     parity ^= 1;
 }

@@ -16,43 +16,46 @@ namespace nm {
 
 constexpr int NVMAX = 10; // widest block reduction (angular momentum 3 + inertia 6)
 
-template <int BLOCK_, int TPA_, typename IdxT_, bool LIST_LDS_, bool SAVE_LDS_>
+// Diagnostic build only (-DNM_PROF, never the shipped library): shader-clock stamps per section, summed by lane 0
+// of each workgroup into KParams::prof[slot][NM_PROF_SLOTS].
+#ifdef NM_PROF
+#define NM_PROF_SLOTS 16
+#define PROF_DECL unsigned long long prof_acc[NM_PROF_SLOTS] = {}; unsigned long long prof_t0 = 0;
+#define PROF_BEGIN() do { __builtin_amdgcn_sched_barrier(0); prof_t0 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PROF_END(k) do { __builtin_amdgcn_sched_barrier(0); prof_acc[k] += __builtin_readcyclecounter() - prof_t0; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PROF_DECL
+#define PROF_BEGIN() do { } while (0)
+#define PROF_END(k) do { } while (0)
+#endif
+
+// NMAX (array stride) and MAXNB (neighbour slots per atom) are compile-time so that every LDS array sits at a
+// constant offset: no address registers are needed for them (with run-time strides the eighteen array bases were
+// spilled to scratch and reloaded inside the pair loop).
+template <int BLOCK_, int TPA_, int NMAX_, int MAXNB_, typename IdxT_, bool LIST_LDS_, bool SAVE_LDS_>
 struct Cfg {
-    static constexpr int BLOCK = BLOCK_, TPA = TPA_, NW = BLOCK_ / 64, G = BLOCK_ / TPA_;
+    static constexpr int BLOCK = BLOCK_, TPA = TPA_, NW = BLOCK_ / 64, G = BLOCK_ / TPA_, NMAX = NMAX_, MAXNB = MAXNB_;
     static constexpr bool LIST_LDS = LIST_LDS_, SAVE_LDS = SAVE_LDS_;
     using IdxT = IdxT_;
+    static constexpr size_t pad8(size_t n) { return (n + 7) & ~(size_t)7; }
+    static constexpr size_t A3 = (size_t)3 * NMAX * sizeof(double);
+    static constexpr size_t OFF_POS = 0, OFF_VEL = A3, OFF_FRC = 2 * A3;
+    static constexpr size_t OFF_SAV = 3 * A3, OFF_SAVV = 4 * A3, OFF_X0 = 5 * A3; // only when SAVE_LDS
+    static constexpr size_t OFF_RED = SAVE_LDS ? 6 * A3 : 3 * A3;
+    static constexpr size_t OFF_CNT = OFF_RED + (size_t)2 * NW * NVMAX * sizeof(double);
+    static constexpr size_t OFF_IMG = OFF_CNT + pad8((size_t)NMAX * sizeof(unsigned short));
+    static constexpr size_t OFF_SIMG = OFF_IMG + pad8((size_t)3 * NMAX);
+    static constexpr size_t OFF_NBR = SAVE_LDS ? OFF_SIMG + pad8((size_t)3 * NMAX) : OFF_SIMG;
+    static constexpr size_t LDS_BYTES = LIST_LDS ? OFF_NBR + pad8((size_t)MAXNB * NMAX * sizeof(IdxT)) : OFF_NBR;
+    // per-slot global spill when the saved copies do not fit in LDS: sav, savv, x0 (9 NMAX doubles) + saved images
+    static constexpr size_t AUX_DOUBLES = SAVE_LDS ? 0 : (size_t)9 * NMAX + ((size_t)3 * NMAX + 7) / 8;
+    static constexpr size_t NBR_G_ELEMS = LIST_LDS ? 0 : (size_t)MAXNB * NMAX; // per-slot global list
 };
-
-struct Layout {
-    size_t pos, vel, frc, sav, savv, x0, red, cnt, img, simg, nbr, total; // byte offsets into dynamic LDS
-    size_t aux_doubles;                                                     // per-slot global spill (doubles)
-};
-
-template <class C>
-__host__ __device__ inline Layout make_layout(int N, int maxnb)
-{
-    Layout l{};
-    size_t o = 0;
-    const size_t a3 = (size_t)3 * N * sizeof(double);
-    l.pos = o; o += a3;
-    l.vel = o; o += a3;
-    l.frc = o; o += a3;
-    if (C::SAVE_LDS) { l.sav = o; o += a3; l.savv = o; o += a3; l.x0 = o; o += a3; }
-    l.red = o; o += (size_t)2 * C::NW * NVMAX * sizeof(double);
-    l.cnt = o; o += (((size_t)N * sizeof(unsigned short)) + 7) & ~(size_t)7;
-    l.img = o; o += (((size_t)3 * N) + 7) & ~(size_t)7;
-    if (C::SAVE_LDS) { l.simg = o; o += (((size_t)3 * N) + 7) & ~(size_t)7; }
-    if (C::LIST_LDS) { l.nbr = o; o += (((size_t)maxnb * N * sizeof(typename C::IdxT)) + 7) & ~(size_t)7; }
-    l.total = o;
-    // spill: sav, savv, x0 (9N doubles) + saved images (3N bytes, rounded up to doubles)
-    l.aux_doubles = C::SAVE_LDS ? 0 : (size_t)9 * N + ((size_t)3 * N + 7) / 8;
-    return l;
-}
 
 template <class C>
 struct Replica {
     using IdxT = typename C::IdxT;
-    static constexpr int BLOCK = C::BLOCK, TPA = C::TPA, NW = C::NW, G = C::G;
+    static constexpr int BLOCK = C::BLOCK, TPA = C::TPA, NW = C::NW, G = C::G, NMAX = C::NMAX, MAXNB = C::MAXNB;
 
     const KParams &p;
     const int tid, N, gslot;
@@ -70,28 +73,28 @@ struct Replica {
     const double *tape = nullptr;
     int tpos = 0, tlen = 0;
     double st_evals = 0.0, st_rebuilds = 0.0, st_eevals = 0.0, st_pairs = 0.0;
+    PROF_DECL
 
     __device__ Replica(const KParams &p_, unsigned char *smem, int slot)
         : p(p_), tid(threadIdx.x), N(p_.N), gslot(p_.slot0 + slot)
     {
-        const Layout l = make_layout<C>(N, p.maxnb);
-        px = (double *)(smem + l.pos); py = px + N; pz = py + N;
-        vx = (double *)(smem + l.vel); vy = vx + N; vz = vy + N;
-        fx = (double *)(smem + l.frc); fy = fx + N; fz = fy + N;
-        red = (double *)(smem + l.red);
-        cnt = (unsigned short *)(smem + l.cnt);
-        im = (signed char *)(smem + l.img);
+        px = (double *)(smem + C::OFF_POS); py = px + NMAX; pz = py + NMAX;
+        vx = (double *)(smem + C::OFF_VEL); vy = vx + NMAX; vz = vy + NMAX;
+        fx = (double *)(smem + C::OFF_FRC); fy = fx + NMAX; fz = fy + NMAX;
+        red = (double *)(smem + C::OFF_RED);
+        cnt = (unsigned short *)(smem + C::OFF_CNT);
+        im = (signed char *)(smem + C::OFF_IMG);
         if constexpr (C::SAVE_LDS) {
-            sx = (double *)(smem + l.sav); svx = (double *)(smem + l.savv); x0 = (double *)(smem + l.x0);
-            sim = (signed char *)(smem + l.simg);
+            sx = (double *)(smem + C::OFF_SAV); svx = (double *)(smem + C::OFF_SAVV); x0 = (double *)(smem + C::OFF_X0);
+            sim = (signed char *)(smem + C::OFF_SIMG);
         } else {
-            double *a = p.aux_g + (size_t)slot * l.aux_doubles;
-            sx = a; svx = a + 3 * (size_t)N; x0 = a + 6 * (size_t)N;
-            sim = (signed char *)(a + 9 * (size_t)N);
+            double *a = p.aux_g + (size_t)slot * C::AUX_DOUBLES;
+            sx = a; svx = a + 3 * (size_t)NMAX; x0 = a + 6 * (size_t)NMAX;
+            sim = (signed char *)(a + 9 * (size_t)NMAX);
         }
-        sy = sx + N; sz = sy + N; svy = svx + N; svz = svy + N; y0 = x0 + N; z0 = y0 + N;
-        if constexpr (C::LIST_LDS) nbr = (IdxT *)(smem + l.nbr);
-        else nbr = (IdxT *)p.nbr_g + (size_t)slot * p.maxnb * N;
+        sy = sx + NMAX; sz = sy + NMAX; svy = svx + NMAX; svz = svy + NMAX; y0 = x0 + NMAX; z0 = y0 + NMAX;
+        if constexpr (C::LIST_LDS) nbr = (IdxT *)(smem + C::OFF_NBR);
+        else nbr = (IdxT *)p.nbr_g + (size_t)slot * C::NBR_G_ELEMS;
         if (p.tape) { tape = p.tape + p.tape_off[slot]; tlen = p.tape_off[slot + 1] - p.tape_off[slot]; }
     }
 
@@ -219,11 +222,11 @@ struct Replica {
                 if (in) {
                     const int r = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (r < p.maxnb) nbr[(size_t)r * N + i] = (IdxT)j;
+                    if (r < MAXNB) nbr[(size_t)r * NMAX + i] = (IdxT)j;
                 }
                 base += __popcll(m);
             }
-            if (base > p.maxnb) { ovf = 1; base = p.maxnb; }
+            if (base > MAXNB) { ovf = 1; base = MAXNB; }
             if (lane == 0) cnt[i] = (unsigned short)base;
         }
         for (int i = tid; i < N; i += BLOCK) { x0[i] = px[i]; y0[i] = py[i]; z0[i] = pz[i]; }
@@ -233,15 +236,77 @@ struct Replica {
         if (__syncthreads_or(ovf)) status |= ST_LIST_OVERFLOW;
     }
 
+    // 1/r2 by v_rcp_f64 + two Newton steps (about 1 ulp) instead of the 12-instruction IEEE division sequence
+    __device__ __forceinline__ double recip(double a)
+    {
+        double y = __builtin_amdgcn_rcp(a);
+        double e = __builtin_fma(-a, y, 1.0);
+        y = __builtin_fma(y, e, y);
+        e = __builtin_fma(-a, y, 1.0);
+        return __builtin_fma(y, e, y);
+    }
+
+    // One listed neighbour: branch-free (a wave almost always has lanes inside the cutoff, so predication costs
+    // nothing and lets two neighbours' instruction streams interleave).
+    template <bool WANT_E>
+    __device__ __forceinline__ void pair_one(int j, double xi, double yi, double zi, double invL, double rc2, bool valid,
+                                             double &ax, double &ay, double &az, double &e, double &w, double &np)
+    {
+        double dx = xi - px[j], dy = yi - py[j], dz = zi - pz[j];
+        dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
+        const double r2 = dx * dx + dy * dy + dz * dz;
+        const bool in = valid && (r2 < rc2);
+        const double r2i = recip(r2);
+        const double r6i = r2i * r2i * r2i;
+        const double fp = in ? r6i * (48.0 * r6i - 24.0) * r2i : 0.0;
+        ax += dx * fp; ay += dy * fp; az += dz * fp;
+        if (WANT_E) {
+            e += in ? r6i * (4.0 * r6i - 4.0) : 0.0;
+            w += r2 * fp;
+            np += in ? 1.0 : 0.0;
+        }
+    }
+
+    template <bool WANT_E>
+    __device__ __forceinline__ void pair_loop(double invL, double &eacc, double &wacc, double &nacc)
+    {
+        const int g = tid / TPA, sub = tid - g * TPA;
+        const double rc2 = p.rc * p.rc;
+        for (int i0 = 0; i0 < N; i0 += G) { // uniform trip count keeps the shuffles below convergent
+            const int i = i0 + g;
+            double ax = 0.0, ay = 0.0, az = 0.0, e = 0.0, w = 0.0, np = 0.0;
+            if (i < N) {
+                const double xi = px[i], yi = py[i], zi = pz[i];
+                const int c = cnt[i];
+                for (int s = sub; s < c; s += 2 * TPA) { // two neighbours per trip for instruction-level parallelism
+                    const bool v1 = (s + TPA) < c;
+                    const int j0 = nbr[(size_t)s * NMAX + i];
+                    const int j1 = v1 ? (int)nbr[(size_t)(s + TPA) * NMAX + i] : j0;
+                    pair_one<WANT_E>(j0, xi, yi, zi, invL, rc2, true, ax, ay, az, e, w, np);
+                    pair_one<WANT_E>(j1, xi, yi, zi, invL, rc2, v1, ax, ay, az, e, w, np);
+                }
+            }
+#pragma unroll
+            for (int off = TPA / 2; off >= 1; off >>= 1) {
+                ax += __shfl_xor(ax, off, 64); ay += __shfl_xor(ay, off, 64); az += __shfl_xor(az, off, 64);
+                if (WANT_E) { e += __shfl_xor(e, off, 64); w += __shfl_xor(w, off, 64); np += __shfl_xor(np, off, 64); }
+            }
+            if (i < N && sub == 0) { fx[i] = ax; fy[i] = ay; fz[i] = az; eacc += e; wacc += w; nacc += np; }
+        }
+    }
+
     // ------------------------------------------------------------------ lj/cut 2.5 energy, forces, virial
     // pair_lj_cut: r2inv, r6inv, fpair = r6inv*(48 r6inv - 24)*r2inv, evdwl = r6inv*(4 r6inv - 4), no shift/tail.
     // Full (both-direction) list: thread group (i, sub) owns f_i, no scatter, no atomics, fixed summation order.
     __device__ void eval(bool want_e)
     {
+        PROF_BEGIN();
         __syncthreads(); // positions written by their owners are visible; previous readers are done
+        PROF_END(0);
         if (!(L >= 2.0 * p.rc)) { status |= ST_BOX_TOO_SMALL; return; } // minimum-image limit
         bool need = !list_ok;
         const double invL = 1.0 / L;
+        PROF_BEGIN();
         if (!need) {
             // the list built at (x0, L0) still covers every pair within rc of the affinely rescaled reference if
             // max_i |x_i - (L/L0) x0_i| <= ((L/L0)(rc+skin) - rc)/2
@@ -255,40 +320,17 @@ struct Replica {
             }
             need = __syncthreads_or(bad);
         }
+        PROF_END(1);
+        PROF_BEGIN();
         if (need) rebuild();
+        PROF_END(2);
 
-        const int g = tid / TPA, sub = tid - g * TPA;
-        const double rc2 = p.rc * p.rc;
         double eacc = 0.0, wacc = 0.0, nacc = 0.0;
-        for (int i0 = 0; i0 < N; i0 += G) { // uniform trip count keeps the shuffles below convergent
-            const int i = i0 + g;
-            double ax = 0.0, ay = 0.0, az = 0.0, e = 0.0, w = 0.0, np = 0.0;
-            if (i < N) {
-                const double xi = px[i], yi = py[i], zi = pz[i];
-                const int c = cnt[i];
-                for (int s = sub; s < c; s += TPA) {
-                    const int j = nbr[(size_t)s * N + i];
-                    double dx = xi - px[j], dy = yi - py[j], dz = zi - pz[j];
-                    dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
-                    const double r2 = dx * dx + dy * dy + dz * dz;
-                    if (r2 < rc2) {
-                        const double r2i = 1.0 / r2;
-                        const double r6i = r2i * r2i * r2i;
-                        const double fp = r6i * (48.0 * r6i - 24.0) * r2i;
-                        ax += dx * fp; ay += dy * fp; az += dz * fp;
-                        e += r6i * (4.0 * r6i - 4.0);
-                        w += r2 * fp;
-                        np += 1.0;
-                    }
-                }
-            }
-#pragma unroll
-            for (int off = TPA / 2; off >= 1; off >>= 1) {
-                ax += __shfl_xor(ax, off, 64); ay += __shfl_xor(ay, off, 64); az += __shfl_xor(az, off, 64);
-                if (want_e) { e += __shfl_xor(e, off, 64); w += __shfl_xor(w, off, 64); np += __shfl_xor(np, off, 64); }
-            }
-            if (i < N && sub == 0) { fx[i] = ax; fy[i] = ay; fz[i] = az; eacc += e; wacc += w; nacc += np; }
-        }
+        PROF_BEGIN();
+        if (want_e) pair_loop<true>(invL, eacc, wacc, nacc);
+        else pair_loop<false>(invL, eacc, wacc, nacc);
+        PROF_END(3);
+        PROF_BEGIN();
         st_evals += 1.0;
         if (want_e) {
             double s[3] = { eacc, wacc, nacc };
@@ -299,15 +341,8 @@ struct Replica {
         } else {
             __syncthreads();
         }
+        PROF_END(4);
         fresh = true;
-    }
-
-    // "run 0": remap atoms into the box, (re-neighbour,) forces and thermo.  Skips the evaluation when
-    // nothing moved since the last one (same U, W, f as the reference's repeated run 0).
-    __device__ void setup()
-    {
-        wrap();
-        if (!fresh) eval(true);
     }
 
     // ------------------------------------------------------------------ velocity commands (remcmc:604-606)
@@ -387,31 +422,6 @@ struct Replica {
     }
 
     // ------------------------------------------------------------------ the moves
-    __device__ bool bulk_pmc(uint32_t m, double et, double dx, double &nt, double &na, double &crit)
-    {
-        nt += 1.0;
-        save(false);
-        const double U0 = U, W0 = W, pe = U / et;
-        const uint32_t tag = draw_tag(m);
-        const double a = q6(dx * p.lat);
-        for (int i = tid; i < N; i += BLOCK) { // displace_atoms all random a a a seed units box
-            uint32_t o[4], q[4];
-            philox4x32_10((uint32_t)i, S_DISP_XY, tag, p.step, p.seed, (uint32_t)gslot, o);
-            philox4x32_10((uint32_t)i, S_DISP_Z, tag, p.step, p.seed, (uint32_t)gslot, q);
-            px[i] += a * 2.0 * (u01(o[0], o[1]) - 0.5);
-            py[i] += a * 2.0 * (u01(o[2], o[3]) - 0.5);
-            pz[i] += a * 2.0 * (u01(q[0], q[1]) - 0.5);
-        }
-        fresh = false;
-        setup();
-        const double penew = U / et;
-        crit = penew - pe;
-        const bool acc = metropolis(crit, S_ACC, m, 0);
-        if (acc) na += 1.0;
-        else { restore(false); wrap(); U = U0; W = W0; }
-        return acc;
-    }
-
     // single-particle energy difference against all other atoms (identical to the reference's difference of two
     // full-system energies up to summation order)
     __device__ void delta_single(int k, double ox, double oy, double oz, double nx, double ny, double nz, double &dE, double &dW)
@@ -471,65 +481,19 @@ struct Replica {
         return nacc;
     }
 
-    __device__ bool vmc(uint32_t m, double et, double pf, double dv, double &nt, double &na, double &crit)
-    {
-        nt += 1.0;
-        const double boxl = L, vol = pow(boxl, 3.0);
-        save(false);
-        const double U0 = U, W0 = W, pe = U / et;
-        const double u = draw_scalar(S_VOL, m, 0);
-        const double volnew = exp(log(vol) + 2.0 * (u - 0.5) * dv);
-        const double boxnew = cbrt(volnew);
-        const double scale = boxnew / boxl;
-        for (int i = tid; i < N; i += BLOCK) { px[i] = scale * sx[i]; py[i] = scale * sy[i]; pz[i] = scale * sz[i]; }
-        fresh = false;
-        L = q6(boxnew); // change_box ... %f
-        setup();
-        const double penew = U / et;
-        crit = (penew - pe) + pf * (volnew - vol) - (double)(N + 1) * log(volnew / vol); // remcmc:576
-        const bool acc = metropolis(crit, S_ACC, m, 0);
-        if (acc) na += 1.0;
-        else { L = q6(boxl); restore(false); wrap(); U = U0; W = W0; }
-        return acc;
-    }
-
-    __device__ bool hmc(uint32_t m, double et, double t, double dt, double &nt, double &na, double &crit)
-    {
-        nt += 1.0;
-        const uint32_t tag = draw_tag(m);
-        velocity_create(q6(t), tag);
-        zero_linear();
-        zero_angular();
-        const double h = q6(dt); // timestep %f
-        setup();
-        save(true);
-        const double U0 = U, W0 = W;
-        const double etot = U / et + 0.5 * p.mvv2e * sum_mv2() / et;
-        // run NSTPS: fix nve velocity-Verlet, no remap inside the run
-        const double dtfm = 0.5 * h * p.ftm2v / p.mass;
-        for (int s = 0; s < p.nstps; ++s) {
-            for (int i = tid; i < N; i += BLOCK) {
-                vx[i] += dtfm * fx[i]; vy[i] += dtfm * fy[i]; vz[i] += dtfm * fz[i];
-                px[i] += h * vx[i]; py[i] += h * vy[i]; pz[i] += h * vz[i];
-            }
-            eval(s == p.nstps - 1);
-            if (status & (ST_BOX_TOO_SMALL | ST_LIST_OVERFLOW)) return false;
-            for (int i = tid; i < N; i += BLOCK) { vx[i] += dtfm * fx[i]; vy[i] += dtfm * fy[i]; vz[i] += dtfm * fz[i]; }
-        }
-        const double etotnew = U / et + 0.5 * p.mvv2e * sum_mv2() / et;
-        crit = etotnew - etot;
-        const bool acc = metropolis(crit, S_ACC, m, 0);
-        if (acc) na += 1.0;
-        else { restore(true); wrap(); U = U0; W = W0; }
-        return acc;
-    }
 };
+
+// Phases of the per-replica state machine.  The block kernel is written so that eval() — by far the largest
+// piece of code and the only one whose cost matters — has exactly ONE call site; every move is split into the
+// part before its energy/force evaluation and the part after it.
+enum : int { PH_INIT = 0, PH_BULK = 1, PH_VMC = 2, PH_HMC_START = 3, PH_HMC_STEP = 4 };
 
 // one workgroup = one replica for MOD moves
 template <class C>
 __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int BLOCK = C::BLOCK;
     const int slot = blockIdx.x;
     const int buf = p.slot2buf[slot];
     const int tid = threadIdx.x;
@@ -537,26 +501,9 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
     const int N = p.N;
 
     R.load(buf);
-    if (p.eval_only) { // nm_eval: batched lj_energy_force on the resident states
-        R.L = p.box[buf];
-        R.wrap();
-        R.eval(true);
-        if (tid == 0) {
-            p.evalU[slot] = R.U; p.evalW[slot] = R.W; p.status[slot] |= R.status;
-            double *st = p.stats + 4 * (size_t)slot;
-            st[0] += R.st_evals; st[1] += R.st_rebuilds; st[2] += R.st_eevals; st[3] += R.st_pairs;
-        }
-        if (p.evalF)
-            for (int a = tid; a < 3 * N; a += C::BLOCK) {
-                const int i = a / 3, c = a - 3 * i;
-                p.evalF[(size_t)slot * 3 * N + a] = (c == 0 ? R.fx : c == 1 ? R.fy : R.fz)[i];
-            }
-        return;
-    }
-
-    // init_lammps (remcmc:459-470): change_box %f, scatter x, v, run 0
-    R.L = q6(p.box[buf]);
-    R.setup();
+    // init_lammps (remcmc:459-470): change_box %f, scatter x, v, run 0.  nm_eval uses the box as given.
+    R.L = uniform(p.eval_only ? p.box[buf] : q6(p.box[buf]));
+    R.wrap();
 
     const double et = p.et[slot], pf = p.pf[slot], t = p.tq[slot];
     const double dx = p.steps[3 * buf], dv = p.steps[3 * buf + 1], dt = p.steps[3 * buf + 2];
@@ -564,22 +511,156 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
     double nav = p.count[6 * slot + 3], nth = p.count[6 * slot + 4], nah = p.count[6 * slot + 5];
     const int fatal = ST_BOX_TOO_SMALL | ST_LIST_OVERFLOW;
 
-    for (int m = 0; m < p.mod && !(R.status & fatal); ++m) {
-        const double roll = R.draw_scalar(S_ROLL, (uint32_t)m, 0); // move_mc, remcmc:645
-        double crit = 0.0, branch;
-        int acc;
-        if (roll <= p.ppos) {
-            if (p.bulk) { branch = 0.0; acc = R.bulk_pmc((uint32_t)m, et, dx, ntp, nap, crit); }
-            else { branch = 3.0; acc = R.iter_pmc((uint32_t)m, et, dx, ntp, nap, crit); }
-        } else if (roll <= p.ppos + p.pvol) {
-            branch = 1.0; acc = R.vmc((uint32_t)m, et, pf, dv, ntv, nav, crit);
-        } else {
-            branch = 2.0; acc = R.hmc((uint32_t)m, et, t, dt, nth, nah, crit);
+    // state carried across the evaluation of a move
+    int phase = PH_INIT, m = 0, hstep = 0;
+    bool want_e = true, skip_eval = false;
+    double U0 = 0.0, W0 = 0.0, c_pe = 0.0, c_vol = 0.0, c_volnew = 0.0, c_boxl = 0.0, c_h = 0.0, c_dtfm = 0.0;
+
+    for (;;) {
+        if (!skip_eval) R.eval(want_e);
+        skip_eval = false;
+        if (R.status & fatal) break;
+#ifdef NM_PROF
+        unsigned long long &prof_t0 = R.prof_t0; unsigned long long (&prof_acc)[NM_PROF_SLOTS] = R.prof_acc;
+        const int prof_phase = phase;
+#endif
+        PROF_BEGIN();
+
+        // ---------------- part of the move after its evaluation
+        bool move_done = false, acc = false;
+        double crit = 0.0, branch = 0.0;
+        if (phase == PH_INIT) {
+            if (p.eval_only) { // nm_eval: batched lj_energy_force on the resident states
+                if (tid == 0) {
+                    p.evalU[slot] = R.U; p.evalW[slot] = R.W; p.status[slot] |= R.status;
+                    double *st = p.stats + 4 * (size_t)slot;
+                    st[0] += R.st_evals; st[1] += R.st_rebuilds; st[2] += R.st_eevals; st[3] += R.st_pairs;
+                }
+                if (p.evalF)
+                    for (int a = tid; a < 3 * N; a += BLOCK) {
+                        const int i = a / 3, c = a - 3 * i;
+                        p.evalF[(size_t)slot * 3 * N + a] = (c == 0 ? R.fx : c == 1 ? R.fy : R.fz)[i];
+                    }
+                return;
+            }
+        } else if (phase == PH_BULK) { // bulk_position_mc, remcmc:485-500
+            const double penew = R.U / et;
+            crit = penew - c_pe;
+            acc = R.metropolis(crit, S_ACC, (uint32_t)m, 0);
+            if (acc) nap += 1.0;
+            else { R.restore(false); R.wrap(); R.U = U0; R.W = W0; }
+            branch = 0.0; move_done = true;
+        } else if (phase == PH_VMC) { // volume_mc, remcmc:574-593
+            const double penew = R.U / et;
+            crit = (penew - c_pe) + pf * (c_volnew - c_vol) - (double)(N + 1) * log(c_volnew / c_vol); // remcmc:576
+            acc = R.metropolis(crit, S_ACC, (uint32_t)m, 0);
+            if (acc) nav += 1.0;
+            else { R.L = uniform(q6(c_boxl)); R.restore(false); R.wrap(); R.U = U0; R.W = W0; }
+            branch = 1.0; move_done = true;
+        } else if (phase == PH_HMC_START) { // hamiltonian_mc after its "run 0", remcmc:609-616
+            R.save(true);
+            U0 = R.U; W0 = R.W;
+            c_pe = R.U / et + 0.5 * p.mvv2e * R.sum_mv2() / et; // etot
+            hstep = 0;
+            for (int i = tid; i < N; i += BLOCK) { // fix nve initial_integrate
+                R.vx[i] += c_dtfm * R.fx[i]; R.vy[i] += c_dtfm * R.fy[i]; R.vz[i] += c_dtfm * R.fz[i];
+                R.px[i] += c_h * R.vx[i]; R.py[i] += c_h * R.vy[i]; R.pz[i] += c_h * R.vz[i];
+            }
+            phase = PH_HMC_STEP; want_e = (p.nstps == 1);
+            PROF_END(5 + PH_HMC_START);
+            continue;
+        } else { // PH_HMC_STEP: forces at the new positions are in
+            for (int i = tid; i < N; i += BLOCK) { // final_integrate
+                R.vx[i] += c_dtfm * R.fx[i]; R.vy[i] += c_dtfm * R.fy[i]; R.vz[i] += c_dtfm * R.fz[i];
+            }
+            ++hstep;
+            if (hstep < p.nstps) {
+                for (int i = tid; i < N; i += BLOCK) {
+                    R.vx[i] += c_dtfm * R.fx[i]; R.vy[i] += c_dtfm * R.fy[i]; R.vz[i] += c_dtfm * R.fz[i];
+                    R.px[i] += c_h * R.vx[i]; R.py[i] += c_h * R.vy[i]; R.pz[i] += c_h * R.vz[i];
+                }
+                want_e = (hstep == p.nstps - 1);
+                PROF_END(5 + PH_HMC_STEP);
+                continue;
+            }
+            const double etotnew = R.U / et + 0.5 * p.mvv2e * R.sum_mv2() / et; // remcmc:618-622
+            crit = etotnew - c_pe;
+            acc = R.metropolis(crit, S_ACC, (uint32_t)m, 0);
+            if (acc) nah += 1.0;
+            else { R.restore(true); R.wrap(); R.U = U0; R.W = W0; }
+            branch = 2.0; move_done = true;
         }
-        if (p.trace && tid == 0) {
-            double *tr = p.trace + ((size_t)slot * p.mod + m) * 4;
-            tr[0] = branch; tr[1] = (double)acc; tr[2] = crit; tr[3] = R.U;
+        if (move_done) {
+            if (p.trace && tid == 0) {
+                double *tr = p.trace + ((size_t)slot * p.mod + m) * 4;
+                tr[0] = branch; tr[1] = acc ? 1.0 : 0.0; tr[2] = crit; tr[3] = R.U;
+            }
+            ++m;
         }
+
+        PROF_END(5 + prof_phase);
+        // ---------------- start moves until one needs an evaluation (move_mc, remcmc:643-658)
+        bool pending = false;
+        while (m < p.mod && !pending) {
+            PROF_BEGIN();
+            const double roll = R.draw_scalar(S_ROLL, (uint32_t)m, 0);
+            if (roll <= p.ppos && p.bulk) { // bulk_position_mc, remcmc:477-484
+                ntp += 1.0;
+                R.save(false);
+                U0 = R.U; W0 = R.W; c_pe = R.U / et;
+                const uint32_t tag = R.draw_tag((uint32_t)m);
+                const double a = q6(dx * p.lat);
+                for (int i = tid; i < N; i += BLOCK) { // displace_atoms all random a a a seed units box
+                    uint32_t o[4], q[4];
+                    philox4x32_10((uint32_t)i, S_DISP_XY, tag, p.step, p.seed, (uint32_t)R.gslot, o);
+                    philox4x32_10((uint32_t)i, S_DISP_Z, tag, p.step, p.seed, (uint32_t)R.gslot, q);
+                    R.px[i] += a * 2.0 * (u01(o[0], o[1]) - 0.5);
+                    R.py[i] += a * 2.0 * (u01(o[2], o[3]) - 0.5);
+                    R.pz[i] += a * 2.0 * (u01(q[0], q[1]) - 0.5);
+                }
+                R.fresh = false;
+                R.wrap();
+                phase = PH_BULK; want_e = true; pending = true;
+                PROF_END(10);
+            } else if (roll <= p.ppos) { // iter_position_mc: local energy differences, no full evaluation
+                double c2 = 0.0;
+                const int na = R.iter_pmc((uint32_t)m, et, dx, ntp, nap, c2);
+                if (p.trace && tid == 0) {
+                    double *tr = p.trace + ((size_t)slot * p.mod + m) * 4;
+                    tr[0] = 3.0; tr[1] = (double)na; tr[2] = c2; tr[3] = R.U;
+                }
+                ++m;
+                PROF_END(13);
+            } else if (roll <= p.ppos + p.pvol) { // volume_mc, remcmc:552-573
+                ntv += 1.0;
+                c_boxl = R.L; c_vol = uniform(pow(c_boxl, 3.0));
+                R.save(false);
+                U0 = R.U; W0 = R.W; c_pe = R.U / et;
+                const double u = R.draw_scalar(S_VOL, (uint32_t)m, 0);
+                c_volnew = uniform(exp(log(c_vol) + 2.0 * (u - 0.5) * dv));
+                const double boxnew = cbrt(c_volnew);
+                const double scale = boxnew / c_boxl;
+                for (int i = tid; i < N; i += BLOCK) { R.px[i] = scale * R.sx[i]; R.py[i] = scale * R.sy[i]; R.pz[i] = scale * R.sz[i]; }
+                R.fresh = false;
+                R.L = uniform(q6(boxnew)); // change_box ... %f
+                R.wrap();
+                phase = PH_VMC; want_e = true; pending = true;
+                PROF_END(11);
+            } else { // hamiltonian_mc, remcmc:598-608
+                nth += 1.0;
+                const uint32_t tag = R.draw_tag((uint32_t)m);
+                R.velocity_create(q6(t), tag);
+                R.zero_linear();
+                R.zero_angular();
+                c_h = uniform(q6(dt)); // timestep %f
+                c_dtfm = 0.5 * c_h * p.ftm2v / p.mass;
+                R.wrap(); // run 0
+                phase = PH_HMC_START; want_e = true; pending = true;
+                skip_eval = R.fresh; // nothing moved since the last evaluation: same U, W, f
+                PROF_END(12);
+            }
+        }
+        if (!pending) break;
     }
 
     // lammps_extract (remcmc:377-391) and the acceptance ratios (remcmc:685-688)
@@ -606,6 +687,9 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
         p.status[slot] |= R.status;
         double *st = p.stats + 4 * (size_t)slot;
         st[0] += R.st_evals; st[1] += R.st_rebuilds; st[2] += R.st_eevals; st[3] += R.st_pairs;
+#ifdef NM_PROF
+        if (p.prof) for (int q = 0; q < NM_PROF_SLOTS; ++q) p.prof[(size_t)slot * NM_PROF_SLOTS + q] += R.prof_acc[q];
+#endif
     }
 }
 
