@@ -76,6 +76,10 @@ int nm_set_state(nm_ctx *ctx, int k0, int nk, const double *x, const double *v, 
                  const double *dxdvdt);
 int nm_get_state(nm_ctx *ctx, int k0, int nk, double *x, double *v, double *box, double *dxdvdt);
 
+/* thermo scalars carried by a state list (entries 3,4,5,6,8 of remcmc:432-433): th[nk][5] = temp, pe, ke, virial, vol.
+   Needed when states come from a restart file and the first thing the reference does is replica_exchange (remcmc:966-968). */
+int nm_set_thermo(nm_ctx *ctx, int k0, int nk, const double *th);
+
 /* cycle index STEP of the main loop (remcmc:977); selects the RNG counter block. nm_run_block does not advance it. */
 int nm_set_step(nm_ctx *ctx, uint32_t step);
 

@@ -302,6 +302,18 @@ int nm_set_state(nm_ctx *c, int k0, int nk, const double *x, const double *v, co
     return NM_OK;
 }
 
+int nm_set_thermo(nm_ctx *c, int k0, int nk, const double *th)
+{
+    if (!c || !th || k0 < 0 || nk < 0 || k0 + nk > c->nslots) return fail(c, NM_ERR_ARG, "nm_set_thermo: bad argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    std::vector<int> m;
+    int rc = slot_map(c, m);
+    if (rc) return rc;
+    for (int q = 0; q < nk; ++q)
+        HIPCHK(c, hipMemcpy(c->d_therm + 5 * (size_t)m[k0 + q], th + 5 * q, 5 * sizeof(double), hipMemcpyHostToDevice));
+    return NM_OK;
+}
+
 int nm_get_state(nm_ctx *c, int k0, int nk, double *x, double *v, double *box, double *dxdvdt)
 {
     if (!c || k0 < 0 || nk < 0 || k0 + nk > c->nslots) return fail(c, NM_ERR_ARG, "nm_get_state: slot range");

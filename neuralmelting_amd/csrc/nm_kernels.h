@@ -43,12 +43,13 @@ struct Cfg {
     static constexpr size_t OFF_SAV = 3 * A3, OFF_SAVV = 4 * A3, OFF_X0 = 5 * A3; // only when SAVE_LDS
     static constexpr size_t OFF_RED = SAVE_LDS ? 6 * A3 : 3 * A3;
     static constexpr size_t OFF_CNT = OFF_RED + (size_t)2 * NW * NVMAX * sizeof(double);
+    // image flags (int16) and the iter-PMC wrap counts (int8): in LDS with the saved copies, else in the global spill
     static constexpr size_t OFF_IMG = OFF_CNT + pad8((size_t)NMAX * sizeof(unsigned short));
-    static constexpr size_t OFF_SIMG = OFF_IMG + pad8((size_t)3 * NMAX);
-    static constexpr size_t OFF_NBR = SAVE_LDS ? OFF_SIMG + pad8((size_t)3 * NMAX) : OFF_SIMG;
+    static constexpr size_t OFF_WN = OFF_IMG + pad8((size_t)3 * NMAX * sizeof(short));
+    static constexpr size_t OFF_NBR = SAVE_LDS ? OFF_WN + pad8((size_t)3 * NMAX) : OFF_IMG;
     static constexpr size_t LDS_BYTES = LIST_LDS ? OFF_NBR + pad8((size_t)MAXNB * NMAX * sizeof(IdxT)) : OFF_NBR;
-    // per-slot global spill when the saved copies do not fit in LDS: sav, savv, x0 (9 NMAX doubles) + saved images
-    static constexpr size_t AUX_DOUBLES = SAVE_LDS ? 0 : (size_t)9 * NMAX + ((size_t)3 * NMAX + 7) / 8;
+    // per-slot global spill when the saved copies do not fit in LDS: sav, savv, x0 (9 NMAX doubles) + images + wrap counts
+    static constexpr size_t AUX_DOUBLES = SAVE_LDS ? 0 : (size_t)9 * NMAX + ((size_t)3 * NMAX * 3 + 7) / 8;
     static constexpr size_t NBR_G_ELEMS = LIST_LDS ? 0 : (size_t)MAXNB * NMAX; // per-slot global list
 };
 
@@ -61,7 +62,8 @@ struct Replica {
     const int tid, N, gslot;
     double *px, *py, *pz, *vx, *vy, *vz, *fx, *fy, *fz;
     double *sx, *sy, *sz, *svx, *svy, *svz, *x0, *y0, *z0;
-    signed char *im, *sim;
+    short *im;       // LAMMPS image flags
+    signed char *wn; // wrap counts of the coordinates gathered at the start of an iter-PMC move
     unsigned short *cnt;
     IdxT *nbr;
     double *red;
@@ -83,14 +85,15 @@ struct Replica {
         fx = (double *)(smem + C::OFF_FRC); fy = fx + NMAX; fz = fy + NMAX;
         red = (double *)(smem + C::OFF_RED);
         cnt = (unsigned short *)(smem + C::OFF_CNT);
-        im = (signed char *)(smem + C::OFF_IMG);
         if constexpr (C::SAVE_LDS) {
             sx = (double *)(smem + C::OFF_SAV); svx = (double *)(smem + C::OFF_SAVV); x0 = (double *)(smem + C::OFF_X0);
-            sim = (signed char *)(smem + C::OFF_SIMG);
+            im = (short *)(smem + C::OFF_IMG);
+            wn = (signed char *)(smem + C::OFF_WN);
         } else {
             double *a = p.aux_g + (size_t)slot * C::AUX_DOUBLES;
             sx = a; svx = a + 3 * (size_t)NMAX; x0 = a + 6 * (size_t)NMAX;
-            sim = (signed char *)(a + 9 * (size_t)NMAX);
+            im = (short *)(a + 9 * (size_t)NMAX);
+            wn = (signed char *)(im + 3 * (size_t)NMAX);
         }
         sy = sx + NMAX; sz = sy + NMAX; svy = svx + NMAX; svz = svy + NMAX; y0 = x0 + NMAX; z0 = y0 + NMAX;
         if constexpr (C::LIST_LDS) nbr = (IdxT *)(smem + C::OFF_NBR);
@@ -157,36 +160,37 @@ struct Replica {
     // ------------------------------------------------------------------ per-atom elementwise phases
     // Ownership: atom i belongs to thread i % BLOCK in every elementwise phase, so these need no barrier
     // among themselves; eval() opens with one.
-    __device__ __forceinline__ void wrap1(double &x, signed char &ig)
+    __device__ __forceinline__ int wrap1(double &x) // domain->remap of one coordinate; returns the image increment
     {
-        if (x < 0.0 || x >= L) { // domain->remap
+        int d = 0;
+        if (x < 0.0 || x >= L) {
             const double nb = floor(x / L);
             x -= nb * L;
-            int d = (int)nb;
+            d = (int)nb;
             if (x >= L) { x -= L; d += 1; }
             if (x < 0.0) x = 0.0;
-            ig = (signed char)(ig + d);
         }
+        return d;
     }
     __device__ void wrap()
     {
         for (int i = tid; i < N; i += BLOCK) {
-            wrap1(px[i], im[3 * i]); wrap1(py[i], im[3 * i + 1]); wrap1(pz[i], im[3 * i + 2]);
+            im[3 * i] = (short)(im[3 * i] + wrap1(px[i]));
+            im[3 * i + 1] = (short)(im[3 * i + 1] + wrap1(py[i]));
+            im[3 * i + 2] = (short)(im[3 * i + 2] + wrap1(pz[i]));
         }
     }
     __device__ void save(bool with_v)
     {
         for (int i = tid; i < N; i += BLOCK) {
             sx[i] = px[i]; sy[i] = py[i]; sz[i] = pz[i];
-            sim[3 * i] = im[3 * i]; sim[3 * i + 1] = im[3 * i + 1]; sim[3 * i + 2] = im[3 * i + 2];
             if (with_v) { svx[i] = vx[i]; svy[i] = vy[i]; svz[i] = vz[i]; }
         }
     }
     __device__ void restore(bool with_v)
     {
         for (int i = tid; i < N; i += BLOCK) {
-            px[i] = sx[i]; py[i] = sy[i]; pz[i] = sz[i];
-            im[3 * i] = sim[3 * i]; im[3 * i + 1] = sim[3 * i + 1]; im[3 * i + 2] = sim[3 * i + 2];
+            px[i] = sx[i]; py[i] = sy[i]; pz[i] = sz[i]; // scatter_atoms: x only, LAMMPS image flags keep what the remaps did
             if (with_v) { vx[i] = svx[i]; vy[i] = svy[i]; vz[i] = svz[i]; }
         }
         fresh = false;
@@ -444,10 +448,20 @@ struct Replica {
         dE = s[0]; dW = s[1];
     }
 
+    // iter_position_mc (remcmc:505-549) with single-particle energy differences instead of N full evaluations.
+    // Reference mode (iter_revert = 0) follows the reference literally: the coordinates gathered at move start stay on the
+    // "Python side" un-remapped, every trial re-sends them and runs `run 0` (twice when the trial is rejected, remcmc:541-542),
+    // so LAMMPS remaps a stale out-of-box coordinate again each time: its image flag grows by its wrap count per run until the
+    // atom's own trial replaces it.  A rejected trial is not undone (`od` aliases `x`, remcmc:522-525).
     __device__ int iter_pmc(uint32_t m, double et, double dx, double &nt, double &na, double &crit)
     {
-        int nacc = 0;
-        wrap(); // one consistent remap at move start (image flags under iter PMC)
+        int nacc = 0, runs = 0;
+        if (p.iter_revert) wrap(); // corrected mode: one consistent remap at move start
+        else
+            for (int i = tid; i < N; i += BLOCK) { // wrap counts of the gathered coordinates
+                double a = px[i], b = py[i], c = pz[i];
+                wn[3 * i] = (signed char)wrap1(a); wn[3 * i + 1] = (signed char)wrap1(b); wn[3 * i + 2] = (signed char)wrap1(c);
+            }
         __syncthreads();
         const double boxl = L;
         for (int k = 0; k < N; ++k) {
@@ -471,16 +485,23 @@ struct Replica {
             const bool acc = metropolis(de, S_ITER_ACC, m, (uint32_t)k);
             crit = de;
             if (acc) { na += 1.0; ++nacc; }
-            if (acc || !p.iter_revert) { // reference: a rejected trial is not undone (remcmc:522,525,540 aliasing)
-                if (tid == (k % BLOCK)) { px[k] = nx; py[k] = ny; pz[k] = nz; }
+            if (acc || !p.iter_revert) {
+                if (tid == (k % BLOCK)) {
+                    px[k] = nx; py[k] = ny; pz[k] = nz;
+                    if (!p.iter_revert) { // the stale coordinate was remapped by every run 0 so far
+                        im[3 * k] = (short)(im[3 * k] + runs * wn[3 * k]);
+                        im[3 * k + 1] = (short)(im[3 * k + 1] + runs * wn[3 * k + 1]);
+                        im[3 * k + 2] = (short)(im[3 * k + 2] + runs * wn[3 * k + 2]);
+                    }
+                }
                 U = Unew; W += dW;
                 fresh = false;
             }
+            runs += acc ? 1 : 2;
             __syncthreads();
         }
         return nacc;
     }
-
 };
 
 // Phases of the per-replica state machine.  The block kernel is written so that eval() — by far the largest

@@ -100,6 +100,14 @@ class Engine:
         self._chk(self.lib.nm_get_state(self.h, k0, nk, _dp(x), _dp(v), _dp(box), _dp(d)))
         return x, v, box, d
 
+    def set_thermo(self, th, k0=0, nk=None):
+        """th[nk][5] = temp, pe, ke, virial, vol (state-list entries 3,4,5,6,8): for restarts"""
+        nk = self.nslots - k0 if nk is None else nk
+        th = np.ascontiguousarray(th, dtype=np.float64)
+        if th.size != 5 * nk:
+            raise ValueError('bad thermo array')
+        self._chk(self.lib.nm_set_thermo(self.h, k0, nk, _dp(th)))
+
     def set_step(self, step):
         self._chk(self.lib.nm_set_step(self.h, int(step)))
 

@@ -57,7 +57,7 @@ def relax_box(sz, press, el='LJ'):
     return brentq(f, lo, hi, xtol=1e-13, rtol=1e-14)
 
 
-def init_states(sz, P, T, dx, dv, el='LJ', seed=256, row0=0, nrows=None):
+def init_states(sz, P, T, dx, dv, el='LJ', seed=256, row0=0, nrows=None, interpolate=False):
     """STATE for the replicas of pressure rows [row0,row0+nrows): x[ns][3N], v (zeros), box[ns], dxdvdt[ns][3]"""
     P = np.asarray(P, dtype=np.float32)
     T = np.asarray(T, dtype=np.float32)
@@ -77,8 +77,14 @@ def init_states(sz, P, T, dx, dv, el='LJ', seed=256, row0=0, nrows=None):
             rng = np.random.Generator(np.random.Philox(key=[seed, i * nt + j]))
             xx = frac * b + amp * 2.0 * (rng.random((n, 3)) - 0.5)
             xx -= np.floor(xx / b) * b
+            bk = b
+            if interpolate:
+                # -is (remcmc:409-419): expand the volume by exp(0.75 (j+1)/NT) about the origin.  The 1024-step NVE run
+                # with fresh velocities that follows in the reference (remcmc:421-425) is left to the first HMC moves.
+                bk = float(np.cbrt(np.exp(np.log(b ** 3) + 0.75 * (j + 1) / nt)))
+                xx = xx * (bk / b)
             x[k] = xx.reshape(-1)
-            box[k] = b
+            box[k] = bk
     v = np.zeros_like(x)
     d = np.tile(np.array([dx, dv, TIMESTEP[UNITS[el]]]), (ns, 1))
     return x, v, box, d

@@ -1,0 +1,339 @@
+"""Driver with the reference's command line and file formats (scripts/lammps_remcmc.py, "remcmc") on top of the
+MI355X engine.  Same flags (remcmc:22-100), same main loop order (remcmc:959-1001), same `.thrm` / `.traj` /
+`.trgt.npy` / `.rstrt.NNNN.npy` outputs, so lammps_parse.py / lammps_distr.py / lammps_vae.py consume a run
+unchanged.  What differs by design: gen_samples / gen_mc_params / replica_exchange are one kernel launch each
+over all replicas of this rank's pressure rows (include/nm.h) instead of a Dask/joblib fan-out of LAMMPS
+instances; the cluster flags (-p -c -d -q -a -nn -np -w -m -nw -nt -mt) are accepted and ignored — ranks come from
+torch.distributed.run (one process per GPU).
+
+    python -m neuralmelting_amd.remcmc -v -bm -n remcmc_init -e LJ -ss 4 -pn 8 -tn 8 -sn 1024 -sm 128
+"""
+import argparse
+import os
+
+import numpy as np
+
+from . import lattice
+from .lattice import LAT, MASS, TIMESTEP, UNITS
+
+SEED = 256  # remcmc:851 (hard-coded in the reference, not a flag)
+
+
+def parse_args(argv=None):
+    """the reference's 34 flags, same names, defaults and return order (remcmc:22-100)"""
+    parser = argparse.ArgumentParser()
+    parser.add_argument('-v', '--verbose', help='verbose output mode', action='store_true')
+    parser.add_argument('-r', '--restart', help='restart run mode', action='store_true')
+    parser.add_argument('-p', '--parallel', help='parallel run mode (accepted, ignored)', action='store_true')
+    parser.add_argument('-c', '--client', help='dask client run mode (accepted, ignored)', action='store_true')
+    parser.add_argument('-d', '--distributed', help='distributed run mode (accepted, ignored)', action='store_true')
+    parser.add_argument('-is', '--interpolate_states', help='interpolate initial states', action='store_true')
+    parser.add_argument('-bm', '--bulk_move', help='bulk position monte carlo moves', action='store_true')
+    parser.add_argument('-rd', '--restart_dump', help='restart dump frequency', type=int, default=128)
+    parser.add_argument('-rn', '--restart_name', help='restart dump simulation name', type=str, default='remcmc_init')
+    parser.add_argument('-rs', '--restart_step', help='restart dump start step', type=int, default=1024)
+    parser.add_argument('-q', '--queue', help='job submission queue (ignored)', type=str, default='jobqueue')
+    parser.add_argument('-a', '--allocation', help='job submission allocation (ignored)', type=str, default='startup')
+    parser.add_argument('-nn', '--nodes', help='job node count (ignored)', type=int, default=1)
+    parser.add_argument('-np', '--procs_per_node', help='number of processors per node (ignored)', type=int, default=20)
+    parser.add_argument('-w', '--walltime', help='job walltime (ignored)', type=int, default=72)
+    parser.add_argument('-m', '--memory', help='job memory (ignored)', type=int, default=32)
+    parser.add_argument('-nw', '--workers', help='job worker count (ignored: ranks come from torch.distributed.run)',
+                        type=int, default=20)
+    parser.add_argument('-nt', '--threads', help='threads per worker (ignored)', type=int, default=1)
+    parser.add_argument('-mt', '--method', help='parallelization method (ignored)', type=str, default='fork')
+    parser.add_argument('-n', '--name', help='simulation name', type=str, default='remcmc_init')
+    parser.add_argument('-e', '--element', help='simulation element', type=str, default='LJ')
+    parser.add_argument('-ss', '--supercell_size', help='simulation supercell size', type=int, default=5)
+    parser.add_argument('-pn', '--pressure_number', help='number of pressures', type=int, default=16)
+    parser.add_argument('-pr', '--pressure_range', help='pressure range (low and high)', type=float, nargs=2, default=[1, 8])
+    parser.add_argument('-tn', '--temperature_number', help='number of temperatures', type=int, default=16)
+    parser.add_argument('-tr', '--temperature_range', help='temperature range (low and high)', type=float, nargs=2,
+                        default=[0.25, 2.5])
+    parser.add_argument('-sc', '--sample_cutoff', help='sample recording cutoff', type=int, default=0)
+    parser.add_argument('-sn', '--sample_number', help='number of samples to generate', type=int, default=1024)
+    parser.add_argument('-sm', '--sample_mod', help='sample collection frequency', type=int, default=128)
+    parser.add_argument('-pm', '--position_move', help='position monte carlo move probability', type=float, default=0.125)
+    parser.add_argument('-vm', '--volume_move', help='volume monte carlo move probability', type=float, default=0.125)
+    parser.add_argument('-ts', '--timesteps', help='hamiltonian monte carlo timesteps', type=int, default=8)
+    parser.add_argument('-dx', '--pos_displace', help='position displacement (lattice proportion)', type=float,
+                        default=0.03125)
+    parser.add_argument('-dv', '--vol_displace', help='logarithmic volume displacement (logarithmic volume proportion)',
+                        type=float, default=0.03125)
+    args = parser.parse_args(argv)
+    return (args.verbose, args.restart, args.parallel, args.client, args.distributed,
+            args.interpolate_states, args.bulk_move,
+            args.restart_dump, args.restart_name, args.restart_step,
+            args.queue, args.allocation, args.nodes, args.procs_per_node,
+            args.walltime, args.memory,
+            args.workers, args.threads, args.method,
+            args.name, args.element, args.supercell_size,
+            args.pressure_number, *args.pressure_range,
+            args.temperature_number, *args.temperature_range,
+            args.sample_cutoff, args.sample_number, args.sample_mod,
+            args.position_move, args.volume_move, args.timesteps,
+            args.pos_displace, args.vol_displace)
+
+
+def init_constant(P, T, el, i, j):
+    """(et, pf) of one replica, remcmc:114-132, in float64 on the float32-rounded grid values (the NumPy-1.x
+    promotion the reference was written for)"""
+    p, t = float(P[i]), float(T[j])
+    if UNITS[el] == 'real':
+        na = 6.0221409e23
+        kb = 3.29983e-27
+        r = kb * na
+        return r * t, 1e-30 * (1.01325e5 * p) / (4.184e3 * kb * t)
+    if UNITS[el] == 'metal':
+        kb = 8.61733e-5
+        return kb * t, 1e-30 * (1e5 * p) / (1.60218e-19 * kb * t)
+    kb = 1.0
+    return kb * t, p / (kb * t)
+
+
+class Run:
+    """one invocation of the driver: holds what the reference keeps in module globals"""
+
+    def __init__(self, argv=None, cwd=None, rank=0, world=1, device=0):
+        (self.VERBOSE, self.RESTART, _par, _dask, _dist, self.INTSTS, self.BM, self.REFREQ, self.RENAME, self.RESTEP,
+         _q, _a, _nn, _ppn, _w, _m, _nw, _nth, _mt, self.NAME, self.EL, self.SZ, self.NP, self.LP, self.HP,
+         self.NT, self.LT, self.HT, self.CUTOFF, self.NSMPL, self.MOD, self.PPOS, self.PVOL, self.NSTPS,
+         self.DX, self.DV) = parse_args(argv)
+        self.cwd = os.getcwd() if cwd is None else cwd
+        self.rank, self.world, self.device = rank, world, device
+        self.NS = self.NP * self.NT
+        self.NSWPS = self.NSMPL * self.MOD
+        self.PHMC = 1 - self.PPOS - self.PVOL
+        self.P = np.linspace(self.LP, self.HP, self.NP, dtype=np.float32)  # remcmc:895
+        self.T = np.linspace(self.LT, self.HT, self.NT, dtype=np.float32)  # remcmc:897
+        self.DT = TIMESTEP[UNITS[self.EL]]
+        self.PREF = self.cwd + '/%s.%s.%s.lammps' % (self.NAME, self.EL.lower(), LAT[self.EL][0])
+        if LAT[self.EL][0] != 'fcc':
+            raise NotImplementedError('only fcc elements are supported')
+        self.natoms = 4 * self.SZ ** 3
+        # contiguous pressure rows per rank; the exchange never leaves a row (remcmc:782-798)
+        base, extra = divmod(self.NP, world)
+        self.nrows = base + (1 if rank < extra else 0)
+        self.row0 = rank * base + min(rank, extra)
+        self.k0 = self.row0 * self.NT
+        self.nloc = self.nrows * self.NT
+        self.engine = None
+        self.STEP = -1
+
+    # ------------------------------------------------------------------ outputs (remcmc:148-316)
+    def file_prefix(self, i, j):
+        return self.cwd + '/%s.%s.%s.%02d.%02d.lammps' % (self.NAME, self.EL.lower(), LAT[self.EL][0], i, j)
+
+    def init_output(self, k):
+        i, j = divmod(k, self.NT)
+        thrm = self.file_prefix(i, j) + '.thrm'
+        traj = thrm.replace('thrm', 'traj')
+        for f in (thrm, traj):  # the reference means to remove both (its second test repeats `thrm`, remcmc:161-164)
+            if os.path.isfile(f):
+                os.remove(f)
+        return thrm, traj
+
+    def header_text(self, k):
+        """remcmc:176-209"""
+        i, j = divmod(k, self.NT)
+        el = self.EL
+        lines = ['# ---------------------', '# simulation parameters', '# ---------------------',
+                 '# nsmpl:    %d' % self.NSMPL, '# cutoff:   %d' % self.CUTOFF, '# mod:      %d' % self.MOD,
+                 '# nswps:    %d' % self.NSWPS, '# ppos:     %f' % self.PPOS, '# pvol:     %f' % self.PVOL,
+                 '# phmc:     %f' % self.PHMC, '# nstps:    %d' % self.NSTPS, '# seed:     %d' % SEED,
+                 '# ---------------------', '# material properties', '# ---------------------',
+                 '# element:  %s' % el, '# units:    %s' % UNITS[el], '# lattice:  %s' % LAT[el][0],
+                 '# latpar:   %f' % LAT[el][1], '# size:     %d' % self.SZ, '# mass:     %f' % MASS[el],
+                 '# press:    %f' % self.P[i], '# temp:     %f' % self.T[j], '# dx:       %f' % self.DX,
+                 '# dv:       %f' % self.DV, '# dt:       %f' % self.DT,
+                 '# -----------------------------------------------------------------------------------------------',
+                 '# | tmp | pe | ke | vir | vol | dx | dv | dt | ntp | nap | ntv | nav | nth | nah | ap | av | ah |',
+                 '# -----------------------------------------------------------------------------------------------']
+        return '\n'.join(lines) + '\n'
+
+    @staticmethod
+    def thrm_text(row):
+        """one .thrm row: 17 x ' %.4E' (remcmc:235-245)"""
+        return 17 * ' %.4E' % tuple(row) + '\n'
+
+    @staticmethod
+    def traj_text(natoms, box, x):
+        """one .traj frame (remcmc:248-256): 'natoms box' then natoms lines of 3 x ' %.4E'"""
+        x = np.asarray(x).reshape(natoms, 3)
+        body = ''.join([' %.4E %.4E %.4E\n' % (a, b, c) for a, b, c in x])
+        return '%d %.4E\n' % (natoms, box) + body
+
+    def init_outputs(self):
+        self.OUTPUT = {k: self.init_output(k) for k in range(self.k0, self.k0 + self.nloc)}
+
+    def init_headers(self):
+        for k, out in self.OUTPUT.items():
+            with open(out[0], 'w') as f:
+                f.write(self.header_text(k))
+
+    def write_outputs(self, rows, x, box):
+        """write_outputs (remcmc:265-286) for this rank's replicas"""
+        for q in range(self.nloc):
+            thrm, traj = self.OUTPUT[self.k0 + q]
+            with open(thrm, 'a') as f:
+                f.write(self.thrm_text(rows[q]))
+            with open(traj, 'a') as f:
+                f.write(self.traj_text(self.natoms, box[q], x[q]))
+
+    def consolidate_outputs(self):
+        """remcmc:289-316 (rank 0, after every rank finished writing)"""
+        thrm = [self.file_prefix(*divmod(k, self.NT)) + '.thrm' for k in range(self.NS)]
+        traj = [t.replace('thrm', 'traj') for t in thrm]
+        for ext, files in (('.thrm', thrm), ('.traj', traj)):
+            with open(self.PREF + ext, 'w') as out:
+                for k in range(self.NS):
+                    with open(files[k], 'r') as fin:
+                        for line in fin:
+                            out.write(line)
+        for k in range(self.NS):
+            os.remove(thrm[k])
+            os.remove(traj[k])
+
+    # ------------------------------------------------------------------ restart (remcmc:810-828)
+    def state_lists(self):
+        """the reference's STATE: one 21-entry list per local replica (remcmc:432-433, 690-691)"""
+        x, v, box, d = self.engine.get_state()
+        rows = self.engine.thermo()
+        out = []
+        for q in range(self.nloc):
+            r = rows[q]
+            out.append([self.natoms, x[q].copy(), v[q].copy(), r[0], r[1], r[2], r[3], box[q], r[4], d[q, 0], d[q, 1], d[q, 2],
+                        r[8], r[9], r[10], r[11], r[12], r[13], np.float32(r[14]), np.float32(r[15]), np.float32(r[16])])
+        return out
+
+    def restart_file(self, name, step):
+        return self.cwd + '/%s.%s.%s.lammps.rstrt.%04d.npy' % (name, self.EL.lower(), LAT[self.EL][0], step)
+
+    def dump_samples_restart(self):
+        """np.save of the object array NS x 21 (remcmc:821-828); ranks gather through files on the node"""
+        state = self.state_lists()
+        rf = self.restart_file(self.NAME, self.STEP + 1)
+        if self.world == 1:
+            np.save(rf, np.array(state, dtype=object))
+            return
+        part = rf + '.part%03d.npy' % self.rank
+        np.save(part, np.array(state, dtype=object))
+        self.barrier()
+        if self.rank == 0:
+            full = []
+            for r in range(self.world):
+                p = rf + '.part%03d.npy' % r
+                full.extend(list(np.load(p, allow_pickle=True)))
+                os.remove(p)
+            np.save(rf, np.array(full, dtype=object))
+        self.barrier()
+
+    def load_samples_restart(self):
+        """remcmc:810-818 (allow_pickle is required on current NumPy)"""
+        rf = self.restart_file(self.RENAME, self.RESTEP)
+        state = list(np.load(rf, allow_pickle=True))[self.k0:self.k0 + self.nloc]
+        x = np.array([np.asarray(s[1], dtype=np.float64) for s in state])
+        v = np.array([np.asarray(s[2], dtype=np.float64) for s in state])
+        box = np.array([float(s[7]) for s in state])
+        d = np.array([[float(s[9]), float(s[10]), float(s[11])] for s in state])
+        th = np.array([[float(s[3]), float(s[4]), float(s[5]), float(s[6]), float(s[8])] for s in state])
+        return x, v, box, d, th
+
+    # ------------------------------------------------------------------ plumbing
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def log(self, *a):
+        if self.VERBOSE and self.rank == 0:
+            print(*a, flush=True)
+
+    def make_engine(self):
+        from .engine import Engine
+        return Engine(self.natoms, self.P, self.T, element=self.EL, ppos=self.PPOS, pvol=self.PVOL, nstps=self.NSTPS,
+                      bulk=self.BM, seed=SEED, device=self.device, row0=self.row0, nrows=self.nrows)
+
+    # ------------------------------------------------------------------ main (remcmc:834-1001)
+    def main(self):
+        np.random.seed(SEED)
+        if self.rank == 0:
+            np.save(self.PREF + '.virial.trgt.npy', self.P)  # remcmc:903-904
+            np.save(self.PREF + '.temp.trgt.npy', self.T)
+        if self.nloc == 0:  # more ranks than pressure rows: this rank only keeps the collectives company
+            return self._idle()
+        self.engine = self.make_engine()
+        eng = self.engine
+        self.init_outputs()
+        if self.CUTOFF < self.NSMPL:
+            self.init_headers()
+        if self.RESTART:
+            self.log('loading samples from previous dump')
+            x, v, box, d, th = self.load_samples_restart()
+            eng.set_state(x, v, box, d)
+            eng.set_thermo(th)
+            eng.set_step(0xFFFFFFFF)  # the exchange after a restart draws from its own counter block
+            n = eng.exchange()
+            self.log('%d replica exchanges performed' % n)
+        else:
+            self.log('initializing samples')
+            x, v, box, d = lattice.init_states(self.SZ, self.P, self.T, self.DX, self.DV, el=self.EL, seed=SEED,
+                                               row0=self.row0, nrows=self.nrows, interpolate=self.INTSTS)
+            eng.set_state(x, v, box, d)
+            eng.run_block(0)  # "run 0" of init_sample: thermo scalars of the initial states (remcmc:427)
+        self.STEP = -1
+        self.dump_samples_restart()
+        for self.STEP in range(self.NSMPL):
+            eng.set_step(self.STEP)
+            eng.run_block(self.MOD)                       # gen_samples
+            if (self.STEP + 1) > self.CUTOFF:             # remcmc:983-985
+                xs, _, boxs, _ = eng.get_state()
+                self.write_outputs(eng.thermo(), xs, boxs)
+            eng.adapt()                                   # gen_mc_params
+            if (self.STEP + 1) % self.REFREQ == 0:
+                self.dump_samples_restart()               # remcmc:990-992
+            if (self.STEP + 1) != self.NSMPL:             # remcmc:994-995
+                n = eng.exchange(count=bool(self.VERBOSE))
+                if self.VERBOSE:
+                    self.log('%d replica exchanges performed' % n)
+        eng.synchronize()
+        self.barrier()
+        if self.CUTOFF < self.NSMPL and self.rank == 0:
+            self.consolidate_outputs()
+        self.barrier()
+        eng.close()
+
+    def _idle(self):
+        self.barrier()          # dump at STEP = -1
+        self.barrier()
+        for step in range(self.NSMPL):
+            if (step + 1) % self.REFREQ == 0:
+                self.barrier()
+                self.barrier()
+        self.barrier()
+        self.barrier()
+
+
+def main(argv=None):
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        use_gpu = torch.cuda.is_available()
+        if use_gpu:
+            torch.cuda.set_device(local)
+        dist.init_process_group('nccl' if use_gpu else 'gloo')
+    run = Run(argv, rank=rank, world=world, device=local)
+    try:
+        run.main()
+    finally:
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

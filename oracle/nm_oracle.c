@@ -537,7 +537,6 @@ int orc_run_block(orc_sim *s, const orc_block_params *p, double *x, double *v, d
     int rc;
     double *xs = (double *)malloc(3 * (size_t)n * sizeof(double));
     double *vs = (double *)malloc(3 * (size_t)n * sizeof(double));
-    int *is = (int *)malloc(3 * (size_t)n * sizeof(int));
 
     /* init_lammps (remcmc:459-470): new instance, change_box %f, scatter x, v, run 0 */
     memset(s->img, 0, 3 * (size_t)n * sizeof(int));
@@ -556,7 +555,7 @@ int orc_run_block(orc_sim *s, const orc_block_params *p, double *x, double *v, d
             /* bulk_position_mc, remcmc:477-502 */
             branch = 0;
             ntp += 1;
-            orc_get_x(s, xs); orc_get_image(s, is);
+            orc_get_x(s, xs);
             double U0 = s->U, W0 = s->W;
             double pe = s->U / p->et;
             uint32_t tag = draw_tag(&d, (uint32_t)m);
@@ -568,7 +567,7 @@ int orc_run_block(orc_sim *s, const orc_block_params *p, double *x, double *v, d
             acc = metropolis(&d, crit, S_ACC, (uint32_t)m, 0);
             if (acc) nap += 1;
             else {
-                orc_set_x(s, xs); orc_set_image(s, is); /* images restored with x (documented deviation) */
+                orc_set_x(s, xs); /* scatter_atoms restores x only: LAMMPS image flags keep what the remap did */
                 wrap_all(s);
                 s->U = U0; s->W = W0; /* = result of the reference's re-run "run 0" */
             }
@@ -580,8 +579,9 @@ int orc_run_block(orc_sim *s, const orc_block_params *p, double *x, double *v, d
                iter_revert = 1 is the corrected move. */
             branch = 3;
             double boxl = orc_get_box(s);
-            wrap_all(s); /* one consistent remap at move start (deviation: the reference re-sends stale
-                            out-of-box coordinates on every trial, inflating LAMMPS image flags) */
+            if (p->iter_revert) wrap_all(s); /* corrected mode: one consistent remap at move start.  Reference mode keeps the
+                                                gathered (possibly out-of-box) coordinates on the Python side and re-sends them on
+                                                every trial, so LAMMPS remaps them again each time (image flags inflate) */
             orc_get_x(s, xs);
             for (int k = 0; k < n; ++k) {
                 ntp += 1;
@@ -589,7 +589,6 @@ int orc_run_block(orc_sim *s, const orc_block_params *p, double *x, double *v, d
                 double od[3] = { xs[3 * k], xs[3 * k + 1], xs[3 * k + 2] };
                 double U0 = s->U, W0 = s->W;
                 double u3[3];
-                orc_get_image(s, is);
                 if (p->tape) for (int c = 0; c < 3; ++c) u3[c] = draw_scalar(&d, 0, 0, 0); /* rand(3), remcmc:523 */
                 else {
                     uint32_t o[4], q[4];
@@ -609,9 +608,15 @@ int orc_run_block(orc_sim *s, const orc_block_params *p, double *x, double *v, d
                 double de = penew - pe;
                 int a1 = metropolis(&d, de, S_ITER_ACC, (uint32_t)m, (uint32_t)k);
                 if (a1) { nap += 1; acc += 1; }
-                else if (p->iter_revert) {
+                else if (!p->iter_revert) {
+                    /* remcmc:540-542: the "revert" is a no-op on x (aliasing) but still scatters and runs `run 0`:
+                       stale out-of-box coordinates are remapped once more */
+                    orc_set_x(s, xs);
+                    rc = orc_setup(s);
+                    if (rc) goto done;
+                } else {
                     xs[3 * k] = od[0]; xs[3 * k + 1] = od[1]; xs[3 * k + 2] = od[2];
-                    orc_set_x(s, xs); orc_set_image(s, is);
+                    orc_set_x(s, xs);
                     wrap_all(s);
                     s->U = U0; s->W = W0;
                 }
@@ -623,7 +628,7 @@ int orc_run_block(orc_sim *s, const orc_block_params *p, double *x, double *v, d
             ntv += 1;
             double boxl = orc_get_box(s);
             double vol = pow(boxl, 3.0);
-            orc_get_x(s, xs); orc_get_image(s, is);
+            orc_get_x(s, xs);
             double U0 = s->U, W0 = s->W;
             double pe = s->U / p->et;
             double u = draw_scalar(&d, S_VOL, (uint32_t)m, 0);
@@ -641,7 +646,7 @@ int orc_run_block(orc_sim *s, const orc_block_params *p, double *x, double *v, d
             if (acc) nav += 1;
             else {
                 orc_set_box(s, orc_q6(boxl));
-                orc_set_x(s, xs); orc_set_image(s, is);
+                orc_set_x(s, xs);
                 wrap_all(s);
                 s->U = U0; s->W = W0;
             }
@@ -656,7 +661,7 @@ int orc_run_block(orc_sim *s, const orc_block_params *p, double *x, double *v, d
             orc_set_timestep(s, orc_q6(dt));
             rc = orc_setup(s);
             if (rc) goto done;
-            orc_get_x(s, xs); orc_get_v(s, vs); orc_get_image(s, is);
+            orc_get_x(s, xs); orc_get_v(s, vs);
             double U0 = s->U, W0 = s->W;
             double etot = s->U / p->et + orc_ke(s) / p->et;
             rc = orc_run(s, p->nstps);
@@ -666,7 +671,7 @@ int orc_run_block(orc_sim *s, const orc_block_params *p, double *x, double *v, d
             acc = metropolis(&d, crit, S_ACC, (uint32_t)m, 0);
             if (acc) nah += 1;
             else {
-                orc_set_x(s, xs); orc_set_v(s, vs); orc_set_image(s, is);
+                orc_set_x(s, xs); orc_set_v(s, vs);
                 wrap_all(s);
                 s->U = U0; s->W = W0;
             }
@@ -689,7 +694,7 @@ int orc_run_block(orc_sim *s, const orc_block_params *p, double *x, double *v, d
     if (p->tape && d.pos > p->tape_len) rc = -3;
 done:
     if (tape_used) *tape_used = d.pos;
-    free(xs); free(vs); free(is);
+    free(xs); free(vs);
     return rc;
 }
 

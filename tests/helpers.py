@@ -66,3 +66,44 @@ class OracleLoop:
         self.x, self.v, self.box = self.x[perm], self.v[perm], self.box[perm]
         self.thermo, self.d = self.thermo[perm], self.d[perm]
         return swaps, perm, crit
+
+
+class OracleEngine:
+    """TEST-ONLY stand-in with the Engine interface, backed by the oracle, so that the driver's host logic and file
+    formats can be exercised on a machine without a GPU (never used by the product: Run.make_engine builds the HIP one)"""
+
+    def __init__(self, O, run):
+        self.O, self.run = O, run
+        sz = run.SZ
+        self.loop = OracleLoop(O, sz, run.P, run.T, dx=run.DX, dv=run.DV, ppos=run.PPOS, pvol=run.PVOL, nstps=run.NSTPS,
+                               bulk=run.BM, row0=run.row0, nrows=run.nrows)
+        self.nslots = self.loop.ns
+        self.natoms = self.loop.natoms
+        self.step = 0
+
+    def set_state(self, x=None, v=None, box=None, dxdvdt=None, k0=0, nk=None):
+        lp = self.loop
+        if x is not None: lp.x = np.array(x, dtype=np.float64).reshape(lp.ns, -1)
+        if v is not None: lp.v = np.array(v, dtype=np.float64).reshape(lp.ns, -1)
+        if box is not None:
+            lp.box = np.array(box, dtype=np.float64)
+            lp.thermo[:, 4] = lp.box ** 3
+        if dxdvdt is not None: lp.d = np.array(dxdvdt, dtype=np.float64).reshape(lp.ns, 3)
+
+    def set_thermo(self, th, k0=0, nk=None):
+        self.loop.thermo = np.array(th, dtype=np.float64).reshape(self.loop.ns, 5)
+
+    def get_state(self, k0=0, nk=None):
+        lp = self.loop
+        return lp.x.copy(), lp.v.copy(), lp.box.copy(), lp.d.copy()
+
+    def set_step(self, step): self.step = int(step)
+    def run_block(self, mod): self.loop.run_block(mod, self.step)
+    def thermo(self): return self.loop.rows()
+    def adapt(self): self.loop.adapt()
+
+    def exchange(self, count=True):
+        return self.loop.exchange(self.step)[0]
+
+    def synchronize(self): pass
+    def close(self): pass

@@ -1,0 +1,115 @@
+"""the driver (neuralmelting_amd.remcmc): flags, row partition, file formats, restart"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import OracleEngine
+from neuralmelting_amd import remcmc
+
+REF_PARSE = '/root/reference/scripts/lammps_parse.py'
+
+
+def test_parse_args_defaults_and_order():
+    a = remcmc.parse_args([])
+    # remcmc:89-100 order and remcmc:25-85 defaults
+    assert a == (False, False, False, False, False, False, False, 128, 'remcmc_init', 1024, 'jobqueue', 'startup', 1, 20,
+                 72, 32, 20, 1, 'fork', 'remcmc_init', 'LJ', 5, 16, 1, 8, 16, 0.25, 2.5, 0, 1024, 128, 0.125, 0.125, 8,
+                 0.03125, 0.03125)
+    a = remcmc.parse_args('-v -bm -n x -e LJ -ss 4 -pn 8 -pr 2 6 -tn 4 -tr 0.5 1.5 -sc 3 -sn 10 -sm 16 -pm 0.2 -vm 0.1 -ts 4 '
+                          '-dx 0.01 -dv 0.02 -nw 16 -nt 1 -p -c -d -r -rd 5 -rn y -rs 7'.split())
+    assert a[0] and a[6] and a[19] == 'x' and a[21] == 4 and a[22:28] == (8, 2.0, 6.0, 4, 0.5, 1.5)
+    assert a[28:] == (3, 10, 16, 0.2, 0.1, 4, 0.01, 0.02) and a[7:10] == (5, 'y', 7)
+
+
+@pytest.mark.parametrize('npn,world', [(8, 1), (8, 2), (8, 8), (16, 8), (5, 2), (2, 4)])
+def test_row_partition(npn, world):
+    rows = []
+    for r in range(world):
+        run = remcmc.Run(['-pn', str(npn), '-tn', '3', '-ss', '4'], rank=r, world=world)
+        rows.extend(range(run.row0, run.row0 + run.nrows))
+        assert run.k0 == run.row0 * 3 and run.nloc == run.nrows * 3
+    assert rows == list(range(npn))          # contiguous, complete, whole pressure rows only
+
+
+def parse_like_reference(pref, pn, tn):
+    """what lammps_parse.py does with the two consolidated files (lammps_parse.py:44-63, 88-96)"""
+    th = np.loadtxt(pref + '.thrm', dtype=np.float32)
+    assert th.shape[1] == 17
+    cols = [c[:, 0].reshape(pn, tn, -1) for c in np.split(th, 17, 1)]
+    data = [ln.split() for ln in open(pref + '.traj')]
+    two = np.array([v for v in data if len(v) == 2])
+    natoms = two[:, 0].astype(np.uint16).reshape(pn, tn, -1)
+    box = two[:, 1].astype(np.float32)
+    x = np.concatenate([np.array(v).astype(np.float32) for v in data if len(v) == 3])
+    x = x.reshape(pn, tn, natoms.shape[2], natoms[0, 0, 0], 3)
+    return cols, natoms, box, x
+
+
+def run_driver(tmp_path, argv, engine_factory=None):
+    run = remcmc.Run(argv, cwd=str(tmp_path))
+    if engine_factory is not None:
+        run.make_engine = lambda: engine_factory(run)
+    run.main()
+    return run
+
+
+def check_outputs(tmp_path, run, nrec):
+    pref = run.PREF
+    assert np.array_equal(np.load(pref + '.virial.trgt.npy'), run.P) and np.load(pref + '.virial.trgt.npy').dtype == np.float32
+    assert np.array_equal(np.load(pref + '.temp.trgt.npy'), run.T)
+    cols, natoms, box, x = parse_like_reference(pref, run.NP, run.NT)
+    assert cols[0].shape == (run.NP, run.NT, nrec)
+    assert (natoms == run.natoms).all() and x.shape == (run.NP, run.NT, nrec, run.natoms, 3)
+    assert np.isfinite(x).all() and (box > 5.0).all()
+    # per-replica files are consolidated and removed (remcmc:314-316)
+    import re
+    assert not [f for f in os.listdir(tmp_path) if re.search(r'\.\d\d\.\d\d\.lammps\.(thrm|traj)$', f)]
+    # restart dumps: STEP=-1 -> 0000 and every REFREQ (remcmc:975-976, 990-992)
+    st = np.load(run.restart_file(run.NAME, 0), allow_pickle=True)
+    assert st.shape == (run.NS, 21) and st[0][0] == run.natoms and len(st[0][1]) == 3 * run.natoms
+    return cols
+
+
+def test_driver_formats_with_oracle_engine(tmp_path, oracle):
+    """host logic + file layout on a machine without a GPU: the engine is replaced by the oracle IN THIS TEST ONLY"""
+    argv = '-bm -n t1 -e LJ -ss 4 -pn 2 -tn 2 -sn 3 -sm 4 -sc 1 -rd 2'.split()
+    run = run_driver(tmp_path, argv, lambda r: OracleEngine(oracle, r))
+    cols = check_outputs(tmp_path, run, nrec=2)          # STEP+1 > CUTOFF: cycles 2 and 3 are recorded
+    assert os.path.isfile(run.restart_file('t1', 2))
+    if os.path.isfile(REF_PARSE):
+        # the reference's own consumer, unmodified, run as a script on the files just written
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+        subprocess.check_call([sys.executable, REF_PARSE, '-n', 't1', '-e', 'LJ'], cwd=str(tmp_path), env=env)
+        pe = np.load(run.PREF + '.pe.npy')
+        pos = np.load(run.PREF + '.pos.npy')
+        assert pe.shape == (2, 2, 2) and pos.shape == (2, 2, 2, 256, 3)
+        np.testing.assert_array_equal(pe, cols[1])
+
+
+@pytest.mark.gpu
+def test_driver_end_to_end_gpu(tmp_path):
+    argv = '-bm -n g1 -e LJ -ss 4 -pn 2 -tn 4 -sn 4 -sm 8 -sc 0 -rd 2'.split()
+    run = run_driver(tmp_path, argv)
+    cols = check_outputs(tmp_path, run, nrec=4)
+    temp, pe = cols[0], cols[1]
+    assert (pe < 0).all() and (temp > 0).all()
+    # restart from the dump of cycle 4 under a new name: loads, exchanges once, continues (remcmc:966-968)
+    argv2 = '-r -rn g1 -rs 4 -bm -n g2 -e LJ -ss 4 -pn 2 -tn 4 -sn 2 -sm 8 -rd 2'.split()
+    run2 = run_driver(tmp_path, argv2)
+    check_outputs(tmp_path, run2, nrec=2)
+
+
+@pytest.mark.gpu
+def test_driver_matches_oracle_driver(tmp_path, oracle):
+    """same flags through the HIP engine and through the oracle stand-in give the same .thrm rows (5 significant digits)"""
+    argv = '-bm -e LJ -ss 4 -pn 2 -tn 2 -sn 3 -sm 6'.split()
+    a = tmp_path / 'a'; b = tmp_path / 'b'
+    a.mkdir(); b.mkdir()
+    ra = run_driver(a, argv + ['-n', 'a'])
+    rb = run_driver(b, argv + ['-n', 'a'], lambda r: OracleEngine(oracle, r))
+    ta = np.loadtxt(ra.PREF + '.thrm'); tb = np.loadtxt(rb.PREF + '.thrm')
+    np.testing.assert_allclose(ta, tb, rtol=2e-4, atol=1e-4)     # the text carries 5 digits
+    np.testing.assert_array_equal(ta[:, 8:14], tb[:, 8:14])
