@@ -221,7 +221,7 @@ class Run:
         self.barrier()
         if self.rank == 0:
             full = []
-            for r in range(self.world):
+            for r in range(min(self.world, self.NP)):  # ranks beyond the number of pressure rows hold nothing
                 p = rf + '.part%03d.npy' % r
                 full.extend(list(np.load(p, allow_pickle=True)))
                 os.remove(p)
