@@ -19,6 +19,9 @@ namespace {
 #define NM_SMALL_BLOCK 512 // 8 waves: 256 VGPRs per lane, no spills (1024 threads cap at 128 and spilled ~200)
 #define NM_SMALL_TPA 2
 #endif
+// cluster variants of the small kernel: Q workgroups per replica, threads-per-atom scaled so that all 512 threads work
+typedef Cfg<NM_SMALL_BLOCK, 2 * NM_SMALL_TPA, 256, 160, unsigned char, true, true> CfgSmallQ2;
+typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 160, unsigned char, true, true> CfgSmallQ4;
 typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 160, unsigned char, true, true> CfgSmall;     // N <= 256: everything incl. the byte list in LDS
 typedef Cfg<512, 1, 864, 160, unsigned short, false, true> CfgMid;     // N <= 864: list in HBM/L2, saved copies in LDS
 typedef Cfg<512, 1, 2048, 160, unsigned short, false, false> CfgLarge; // N <= 2048: saved copies spill to HBM as well
@@ -32,6 +35,8 @@ struct EvPair { hipEvent_t a, b; bool used; };
 struct nm_ctx {
     nm_config cfg;
     int N, nslots, slot0, kind; // kind: 0 small, 1 mid, 2 large
+    int cus;                    // workgroups per replica (1, 2 or 4; small kernel only)
+    double *d_xbuf; int *d_arrive;
     size_t lds_bytes, aux_doubles;
     double lat, mass, kB, mvv2e, ftm2v, nktv2p, skin;
     uint32_t step;
@@ -89,19 +94,24 @@ void fill_params(const nm_ctx *c, KParams &p)
     p.tape = c->d_tape; p.tape_off = c->d_tape_off;
     p.nbr_g = c->d_nbr; p.aux_g = c->d_aux;
     p.prof = c->d_prof;
+    p.cus = c->cus; p.xbuf = c->d_xbuf; p.arrive = c->d_arrive;
 }
 
 template <class C>
 hipError_t launch_block(const nm_ctx *c, const KParams &p)
 {
-    hipLaunchKernelGGL(nm_block_kernel<C>, dim3(c->nslots), dim3(C::BLOCK), c->lds_bytes, c->stream, p);
+    if (c->cus > 1) { // the cluster's arrival counters start every launch at zero
+        hipError_t e = hipMemsetAsync(c->d_arrive, 0, sizeof(int) * c->nslots, c->stream);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(nm_block_kernel<C>, dim3(c->nslots * c->cus), dim3(C::BLOCK), c->lds_bytes, c->stream, p);
     return hipGetLastError();
 }
 
 hipError_t launch_kind(const nm_ctx *c, const KParams &p)
 {
     switch (c->kind) {
-    case 0: return launch_block<CfgSmall>(c, p);
+    case 0: return c->cus == 4 ? launch_block<CfgSmallQ4>(c, p) : c->cus == 2 ? launch_block<CfgSmallQ2>(c, p) : launch_block<CfgSmall>(c, p);
     case 1: return launch_block<CfgMid>(c, p);
     default: return launch_block<CfgLarge>(c, p);
     }
@@ -126,11 +136,12 @@ int check_status(nm_ctx *c)
         if (st[k]) {
             char buf[256];
             std::snprintf(buf, sizeof buf,
-                          "replica slot %d (global %d) left the supported regime:%s%s%s%s", k, c->slot0 + k,
+                          "replica slot %d (global %d) left the supported regime:%s%s%s%s%s", k, c->slot0 + k,
                           (st[k] & ST_LIST_OVERFLOW) ? " neighbour list overflow;" : "",
                           (st[k] & ST_BOX_TOO_SMALL) ? " box edge < 2*rc (minimum image invalid);" : "",
                           (st[k] & ST_TAPE_EXHAUSTED) ? " rng tape exhausted;" : "",
-                          (st[k] & ST_NONFINITE) ? " non-finite energy;" : "");
+                          (st[k] & ST_NONFINITE) ? " non-finite energy;" : "",
+                          (st[k] & ST_SYNC_TIMEOUT) ? " cluster hand-off timed out (workgroups not co-resident?);" : "");
             return fail(c, NM_ERR_STATE, buf);
         }
     return NM_OK;
@@ -203,6 +214,18 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     } while (0)
     CHK(hipSetDevice(cfg->device));
     CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // Workgroups per replica.  A cluster spins on its peers, so every workgroup of the grid must be resident at once: the
+    // small kernel admits one workgroup per CU (LDS + registers), so nslots*Q must not exceed the CU count (with a margin).
+    c->cus = 1; c->d_xbuf = nullptr; c->d_arrive = nullptr;
+    if (c->kind == 0) {
+        hipDeviceProp_t prop;
+        CHK(hipGetDeviceProperties(&prop, cfg->device));
+        const int cu = prop.multiProcessorCount;
+        int want = 4;
+        if (const char *e = std::getenv("NM_CUS_PER_REPLICA")) want = std::atoi(e);
+        for (int qq : { 4, 2 })
+            if (want >= qq && c->nslots * qq <= cu) { c->cus = qq; break; }
+    }
     const size_t ns = c->nslots, n3 = (size_t)3 * c->N;
     CHK(dalloc(&c->d_x, ns * n3)); CHK(dalloc(&c->d_v, ns * n3));
     CHK(dalloc(&c->d_box, ns)); CHK(dalloc(&c->d_steps, ns * 3)); CHK(dalloc(&c->d_therm, ns * 5));
@@ -220,6 +243,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     c->d_tape = nullptr; c->d_tape_off = nullptr; c->d_trace = nullptr; c->d_nbr = nullptr; c->d_aux = nullptr;
     if (nbr_elems) CHK(hipMalloc(&c->d_nbr, ns * nbr_elems * sizeof(unsigned short)));
     if (c->aux_doubles) CHK(dalloc(&c->d_aux, ns * c->aux_doubles));
+    if (c->cus > 1) { CHK(dalloc(&c->d_xbuf, ns * 2 * CfgSmall::XBUF_DOUBLES)); CHK(dalloc(&c->d_arrive, ns)); }
     CHK(hipMemset(c->d_x, 0, ns * n3 * sizeof(double))); CHK(hipMemset(c->d_v, 0, ns * n3 * sizeof(double)));
     CHK(hipMemset(c->d_box, 0, ns * sizeof(double))); CHK(hipMemset(c->d_steps, 0, ns * 3 * sizeof(double)));
     CHK(hipMemset(c->d_therm, 0, ns * 5 * sizeof(double))); CHK(hipMemset(c->d_count, 0, ns * 6 * sizeof(double)));
@@ -232,7 +256,11 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     CHK(hipMemcpy(c->d_pf, c->h_pf.data(), ns * sizeof(double), hipMemcpyHostToDevice));
     CHK(hipMemcpy(c->d_tq, c->h_tq.data(), ns * sizeof(double), hipMemcpyHostToDevice));
     // dynamic LDS above 64 KiB has to be requested per kernel
-    if (c->kind == 0) CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+    if (c->kind == 0) {
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallQ2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallQ4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+    }
     else if (c->kind == 1) CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgMid>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
     else CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgLarge>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
     c->ev.resize(32);
@@ -250,7 +278,7 @@ int nm_destroy(nm_ctx *c)
     for (auto &e : c->ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     void *ptrs[] = { c->d_x, c->d_v, c->d_box, c->d_steps, c->d_therm, c->d_count, c->d_ratio, c->d_et, c->d_pf, c->d_tq,
                      c->d_stats, c->d_slot2buf, c->d_status, c->d_nswaps, c->d_evalU, c->d_evalW, c->d_evalF, c->d_xcrit,
-                     c->d_xtape, c->d_tape, c->d_tape_off, c->d_trace, c->d_nbr, c->d_aux, c->d_prof };
+                     c->d_xtape, c->d_tape, c->d_tape_off, c->d_trace, c->d_nbr, c->d_aux, c->d_prof, c->d_xbuf, c->d_arrive };
     for (void *q : ptrs) if (q) hipFree(q);
     hipStreamDestroy(c->stream);
     delete c;

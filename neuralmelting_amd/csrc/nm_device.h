@@ -15,7 +15,7 @@ enum : uint32_t { S_ROLL = 0, S_ACC = 1, S_VOL = 2, S_DISP_XY = 3, S_DISP_Z = 4,
                   S_EXCH = 7, S_ITER_XY = 8, S_ITER_Z = 9, S_ITER_ACC = 10 };
 
 // status bits per slot
-enum : int { ST_LIST_OVERFLOW = 1, ST_BOX_TOO_SMALL = 2, ST_TAPE_EXHAUSTED = 4, ST_NONFINITE = 8 };
+enum : int { ST_LIST_OVERFLOW = 1, ST_BOX_TOO_SMALL = 2, ST_TAPE_EXHAUSTED = 4, ST_NONFINITE = 8, ST_SYNC_TIMEOUT = 16 };
 
 struct KParams {
     int N, nslots, slot0;          // atoms, local replicas, global index of local slot 0
@@ -41,6 +41,9 @@ struct KParams {
     void *nbr_g;                   // global neighbour lists (N > 256): [slot][maxnb*N] uint16
     double *aux_g;                 // global spill of the saved copies (large N): [slot][AUX_DOUBLES(N)]
     unsigned long long *prof;      // diagnostic build only
+    int cus;                       // workgroups (CUs) cooperating on one replica
+    double *xbuf;                  // [slot][2][XBUF_DOUBLES]: force slices + partial sums exchanged inside a cluster
+    int *arrive;                   // [slot] arrival counter of the cluster (zeroed before every launch)
 };
 
 // ------------------------------------------------------------------------------------------ Philox4x32-10

@@ -51,6 +51,8 @@ struct Cfg {
     // per-slot global spill when the saved copies do not fit in LDS: sav, savv, x0 (9 NMAX doubles) + images + wrap counts
     static constexpr size_t AUX_DOUBLES = SAVE_LDS ? 0 : (size_t)9 * NMAX + ((size_t)3 * NMAX * 3 + 7) / 8;
     static constexpr size_t NBR_G_ELEMS = LIST_LDS ? 0 : (size_t)MAXNB * NMAX; // per-slot global list
+    static constexpr int QMAX = 8;                                               // most workgroups per replica
+    static constexpr size_t XBUF_DOUBLES = (size_t)3 * NMAX + 4 * QMAX;          // one exchange buffer (there are two per slot)
 };
 
 template <class C>
@@ -60,6 +62,11 @@ struct Replica {
 
     const KParams &p;
     const int tid, N, gslot;
+    // cluster: Q workgroups (one per CU) run the same replica redundantly and split only the pair work by atom range
+    const int Q, q, a0, a1;
+    double *xb;
+    int *arrive;
+    int gen = 0;
     double *px, *py, *pz, *vx, *vy, *vz, *fx, *fy, *fz;
     double *sx, *sy, *sz, *svx, *svy, *svz, *x0, *y0, *z0;
     short *im;       // LAMMPS image flags
@@ -77,9 +84,12 @@ struct Replica {
     double st_evals = 0.0, st_rebuilds = 0.0, st_eevals = 0.0, st_pairs = 0.0;
     PROF_DECL
 
-    __device__ Replica(const KParams &p_, unsigned char *smem, int slot)
-        : p(p_), tid(threadIdx.x), N(p_.N), gslot(p_.slot0 + slot)
+    __device__ Replica(const KParams &p_, unsigned char *smem, int slot, int q_)
+        : p(p_), tid(threadIdx.x), N(p_.N), gslot(p_.slot0 + slot), Q(p_.cus), q(q_), a0((p_.N * q_) / p_.cus),
+          a1((p_.N * (q_ + 1)) / p_.cus)
     {
+        xb = p.xbuf ? p.xbuf + (size_t)slot * 2 * C::XBUF_DOUBLES : nullptr;
+        arrive = p.arrive ? p.arrive + slot : nullptr;
         px = (double *)(smem + C::OFF_POS); py = px + NMAX; pz = py + NMAX;
         vx = (double *)(smem + C::OFF_VEL); vy = vx + NMAX; vz = vy + NMAX;
         fx = (double *)(smem + C::OFF_FRC); fy = fx + NMAX; fz = fy + NMAX;
@@ -211,7 +221,7 @@ struct Replica {
         const int lane = tid & 63, wv = tid >> 6;
         const double invL = 1.0 / L, rl = p.rc + p.skin, rl2 = rl * rl;
         int ovf = 0;
-        for (int i = wv; i < N; i += NW) {
+        for (int i = a0 + wv; i < a1; i += NW) { // this workgroup's rows of the list
             const double xi = px[i], yi = py[i], zi = pz[i];
             int base = 0;
             for (int j0 = 0; j0 < N; j0 += 64) {
@@ -276,10 +286,11 @@ struct Replica {
     {
         const int g = tid / TPA, sub = tid - g * TPA;
         const double rc2 = p.rc * p.rc;
-        for (int i0 = 0; i0 < N; i0 += G) { // uniform trip count keeps the shuffles below convergent
+        double *xg = xb ? xb + (size_t)(gen & 1) * C::XBUF_DOUBLES : nullptr;
+        for (int i0 = a0; i0 < a1; i0 += G) { // uniform trip count keeps the shuffles below convergent
             const int i = i0 + g;
             double ax = 0.0, ay = 0.0, az = 0.0, e = 0.0, w = 0.0, np = 0.0;
-            if (i < N) {
+            if (i < a1) {
                 const double xi = px[i], yi = py[i], zi = pz[i];
                 const int c = cnt[i];
                 for (int s = sub; s < c; s += 2 * TPA) { // two neighbours per trip for instruction-level parallelism
@@ -295,8 +306,71 @@ struct Replica {
                 ax += __shfl_xor(ax, off, 64); ay += __shfl_xor(ay, off, 64); az += __shfl_xor(az, off, 64);
                 if (WANT_E) { e += __shfl_xor(e, off, 64); w += __shfl_xor(w, off, 64); np += __shfl_xor(np, off, 64); }
             }
-            if (i < N && sub == 0) { fx[i] = ax; fy[i] = ay; fz[i] = az; eacc += e; wacc += w; nacc += np; }
+            if (i < a1 && sub == 0) {
+                fx[i] = ax; fy[i] = ay; fz[i] = az; eacc += e; wacc += w; nacc += np;
+                if (Q > 1) { // publish this atom's force to the other workgroups of the cluster (write-through store)
+                    __hip_atomic_store(xg + i, ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(xg + NMAX + i, ay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(xg + 2 * NMAX + i, az, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
+    }
+
+    // ------------------------------------------------------------------ cluster hand-off (Q workgroups per replica)
+    // Every workgroup has just stored the forces of its own atoms (and, below, its partial sums and status bits) with
+    // write-through (sc1) stores into exchange buffer gen&1.  Protocol (MI355X guide, Guideline 16 / hand-off table row 1):
+    // every storing wave drains vmcnt, workgroup barrier, ONE lane adds to the cluster's arrival counter (agent scope),
+    // ONE lane polls it with sc1 loads, workgroup barrier, then every load of the handed-off bytes is an sc1 load.
+    // Two buffers alternate, and a workgroup can only run one evaluation ahead of the slowest (it needs everybody's
+    // arrival), so a buffer is never overwritten while someone still reads it.  The spin is bounded: a cluster that is
+    // not co-resident reports ST_SYNC_TIMEOUT instead of hanging.
+    __device__ void cluster_exchange(bool want_e, double (&s)[3])
+    {
+        double *xg = xb + (size_t)(gen & 1) * C::XBUF_DOUBLES;
+        if (tid == 0) {
+            double *ps = xg + 3 * NMAX + 4 * q;
+            __hip_atomic_store(ps + 0, s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ps + 1, s[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ps + 2, s[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ps + 3, (double)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int timeout = 0;
+        if (tid == 0) {
+            const int target = Q * (gen + 1);
+            __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = wall_clock64(); // 100 MHz
+            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 200000000ull) { timeout = 1; break; } // 2 s
+            }
+        }
+        if (__syncthreads_or(timeout)) { status |= ST_SYNC_TIMEOUT; ++gen; return; }
+        // forces of the atoms the other workgroups own
+        for (int i = tid; i < N; i += BLOCK)
+            if (i < a0 || i >= a1) {
+                fx[i] = __hip_atomic_load(xg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fy[i] = __hip_atomic_load(xg + NMAX + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fz[i] = __hip_atomic_load(xg + 2 * NMAX + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        // partial sums and status bits in workgroup order: identical bits in every workgroup of the cluster
+        double t0s = 0.0, t1s = 0.0, t2s = 0.0;
+        int st = 0;
+        for (int r = 0; r < Q; ++r) {
+            const double *ps = xg + 3 * NMAX + 4 * r;
+            if (want_e) {
+                t0s += __hip_atomic_load(ps + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                t1s += __hip_atomic_load(ps + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                t2s += __hip_atomic_load(ps + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            st |= (int)__hip_atomic_load(ps + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s[0] = uniform(t0s); s[1] = uniform(t1s); s[2] = uniform(t2s);
+        status |= __builtin_amdgcn_readfirstlane(st);
+        ++gen;
+        __syncthreads();
     }
 
     // ------------------------------------------------------------------ lj/cut 2.5 energy, forces, virial
@@ -336,14 +410,14 @@ struct Replica {
         PROF_END(3);
         PROF_BEGIN();
         st_evals += 1.0;
+        double s[3] = { eacc, wacc, nacc };
+        if (want_e) block_sum<3, NW, NVMAX>(s, red, parity); // over this workgroup's atoms
+        if (Q > 1) cluster_exchange(want_e, s);
+        else if (!want_e) __syncthreads();
         if (want_e) {
-            double s[3] = { eacc, wacc, nacc };
-            block_sum<3, NW, NVMAX>(s, red, parity);
             U = 0.5 * s[0]; W = 0.5 * s[1];
             st_eevals += 1.0; st_pairs += 0.5 * s[2];
             if (!(U == U) || isinf(U)) status |= ST_NONFINITE;
-        } else {
-            __syncthreads();
         }
         PROF_END(4);
         fresh = true;
@@ -515,10 +589,16 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int BLOCK = C::BLOCK;
-    const int slot = blockIdx.x;
+    // cluster mapping: with 8 | nslots the Q members of a cluster share blockIdx % 8, i.e. one XCD (and its L2) under the
+    // observed round-robin placement — a speed matter only, the hand-off protocol does not depend on it
+    const int Q = p.cus, b = blockIdx.x;
+    int slot, qq;
+    if ((p.nslots & 7) == 0) { const int r = b >> 3; slot = (b & 7) + 8 * (r / Q); qq = r % Q; }
+    else { slot = b / Q; qq = b % Q; }
     const int buf = p.slot2buf[slot];
     const int tid = threadIdx.x;
-    Replica<C> R(p, smem, slot);
+    Replica<C> R(p, smem, slot, qq);
+    const bool writer = (tid == 0 && qq == 0); // one workgroup of the cluster writes the replica's results
     const int N = p.N;
 
     R.load(buf);
@@ -530,7 +610,7 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
     const double dx = p.steps[3 * buf], dv = p.steps[3 * buf + 1], dt = p.steps[3 * buf + 2];
     double ntp = p.count[6 * slot], nap = p.count[6 * slot + 1], ntv = p.count[6 * slot + 2];
     double nav = p.count[6 * slot + 3], nth = p.count[6 * slot + 4], nah = p.count[6 * slot + 5];
-    const int fatal = ST_BOX_TOO_SMALL | ST_LIST_OVERFLOW;
+    const int fatal = ST_BOX_TOO_SMALL | ST_LIST_OVERFLOW | ST_SYNC_TIMEOUT;
 
     // state carried across the evaluation of a move
     int phase = PH_INIT, m = 0, hstep = 0;
@@ -552,12 +632,12 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
         double crit = 0.0, branch = 0.0;
         if (phase == PH_INIT) {
             if (p.eval_only) { // nm_eval: batched lj_energy_force on the resident states
-                if (tid == 0) {
+                if (writer) {
                     p.evalU[slot] = R.U; p.evalW[slot] = R.W; p.status[slot] |= R.status;
                     double *st = p.stats + 4 * (size_t)slot;
                     st[0] += R.st_evals; st[1] += R.st_rebuilds; st[2] += R.st_eevals; st[3] += R.st_pairs;
                 }
-                if (p.evalF)
+                if (p.evalF && qq == 0)
                     for (int a = tid; a < 3 * N; a += BLOCK) {
                         const int i = a / 3, c = a - 3 * i;
                         p.evalF[(size_t)slot * 3 * N + a] = (c == 0 ? R.fx : c == 1 ? R.fy : R.fz)[i];
@@ -612,7 +692,7 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
             branch = 2.0; move_done = true;
         }
         if (move_done) {
-            if (p.trace && tid == 0) {
+            if (p.trace && writer) {
                 double *tr = p.trace + ((size_t)slot * p.mod + m) * 4;
                 tr[0] = branch; tr[1] = acc ? 1.0 : 0.0; tr[2] = crit; tr[3] = R.U;
             }
@@ -646,7 +726,7 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
             } else if (roll <= p.ppos) { // iter_position_mc: local energy differences, no full evaluation
                 double c2 = 0.0;
                 const int na = R.iter_pmc((uint32_t)m, et, dx, ntp, nap, c2);
-                if (p.trace && tid == 0) {
+                if (p.trace && writer) {
                     double *tr = p.trace + ((size_t)slot * p.mod + m) * 4;
                     tr[0] = 3.0; tr[1] = (double)na; tr[2] = c2; tr[3] = R.U;
                 }
@@ -686,8 +766,8 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
 
     // lammps_extract (remcmc:377-391) and the acceptance ratios (remcmc:685-688)
     const double smv2 = R.sum_mv2();
-    R.store(buf);
-    if (tid == 0) {
+    if (qq == 0) R.store(buf);
+    if (writer) {
         const double dof = 3.0 * N - 3.0;
         const double temp = smv2 * p.mvv2e / (dof * p.kB);
         const double vol3 = R.L * R.L * R.L;
