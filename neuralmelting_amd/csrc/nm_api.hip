@@ -36,7 +36,8 @@ struct nm_ctx {
     nm_config cfg;
     int N, nslots, slot0, kind; // kind: 0 small, 1 mid, 2 large
     int cus;                    // workgroups per replica (1, 2 or 4; small kernel only)
-    double *d_xbuf; int *d_arrive;
+    double *d_xbuf;
+    uint32_t launch_id;
     size_t lds_bytes, aux_doubles;
     double lat, mass, kB, mvv2e, ftm2v, nktv2p, skin;
     uint32_t step;
@@ -94,16 +95,14 @@ void fill_params(const nm_ctx *c, KParams &p)
     p.tape = c->d_tape; p.tape_off = c->d_tape_off;
     p.nbr_g = c->d_nbr; p.aux_g = c->d_aux;
     p.prof = c->d_prof;
-    p.cus = c->cus; p.xbuf = c->d_xbuf; p.arrive = c->d_arrive;
+    p.cus = c->cus; p.xbuf = c->d_xbuf; p.launch_id = c->launch_id;
+    p.dbg = 0;
+    if (const char *e = std::getenv("NM_DBG")) p.dbg = std::atoi(e);
 }
 
 template <class C>
 hipError_t launch_block(const nm_ctx *c, const KParams &p)
 {
-    if (c->cus > 1) { // the cluster's arrival counters start every launch at zero
-        hipError_t e = hipMemsetAsync(c->d_arrive, 0, sizeof(int) * c->nslots, c->stream);
-        if (e != hipSuccess) return e;
-    }
     hipLaunchKernelGGL(nm_block_kernel<C>, dim3(c->nslots * c->cus), dim3(C::BLOCK), c->lds_bytes, c->stream, p);
     return hipGetLastError();
 }
@@ -216,7 +215,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     // Workgroups per replica.  A cluster spins on its peers, so every workgroup of the grid must be resident at once: the
     // small kernel admits one workgroup per CU (LDS + registers), so nslots*Q must not exceed the CU count (with a margin).
-    c->cus = 1; c->d_xbuf = nullptr; c->d_arrive = nullptr;
+    c->cus = 1; c->d_xbuf = nullptr; c->launch_id = 0;
     if (c->kind == 0) {
         hipDeviceProp_t prop;
         CHK(hipGetDeviceProperties(&prop, cfg->device));
@@ -243,7 +242,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     c->d_tape = nullptr; c->d_tape_off = nullptr; c->d_trace = nullptr; c->d_nbr = nullptr; c->d_aux = nullptr;
     if (nbr_elems) CHK(hipMalloc(&c->d_nbr, ns * nbr_elems * sizeof(unsigned short)));
     if (c->aux_doubles) CHK(dalloc(&c->d_aux, ns * c->aux_doubles));
-    if (c->cus > 1) { CHK(dalloc(&c->d_xbuf, ns * 2 * CfgSmall::XBUF_DOUBLES)); CHK(dalloc(&c->d_arrive, ns)); }
+    if (c->cus > 1) { CHK(dalloc(&c->d_xbuf, ns * 2 * CfgSmall::XBUF_DOUBLES)); CHK(hipMemset(c->d_xbuf, 0, ns * 2 * CfgSmall::XBUF_DOUBLES * sizeof(double))); }
     CHK(hipMemset(c->d_x, 0, ns * n3 * sizeof(double))); CHK(hipMemset(c->d_v, 0, ns * n3 * sizeof(double)));
     CHK(hipMemset(c->d_box, 0, ns * sizeof(double))); CHK(hipMemset(c->d_steps, 0, ns * 3 * sizeof(double)));
     CHK(hipMemset(c->d_therm, 0, ns * 5 * sizeof(double))); CHK(hipMemset(c->d_count, 0, ns * 6 * sizeof(double)));
@@ -278,7 +277,7 @@ int nm_destroy(nm_ctx *c)
     for (auto &e : c->ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     void *ptrs[] = { c->d_x, c->d_v, c->d_box, c->d_steps, c->d_therm, c->d_count, c->d_ratio, c->d_et, c->d_pf, c->d_tq,
                      c->d_stats, c->d_slot2buf, c->d_status, c->d_nswaps, c->d_evalU, c->d_evalW, c->d_evalF, c->d_xcrit,
-                     c->d_xtape, c->d_tape, c->d_tape_off, c->d_trace, c->d_nbr, c->d_aux, c->d_prof, c->d_xbuf, c->d_arrive };
+                     c->d_xtape, c->d_tape, c->d_tape_off, c->d_trace, c->d_nbr, c->d_aux, c->d_prof, c->d_xbuf };
     for (void *q : ptrs) if (q) hipFree(q);
     hipStreamDestroy(c->stream);
     delete c;
@@ -364,6 +363,7 @@ int nm_run_block(nm_ctx *c, int mod)
 {
     if (!c || mod < 0) return fail(c, NM_ERR_ARG, "nm_run_block: bad argument");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    ++c->launch_id;
     KParams p;
     fill_params(c, p);
     p.mod = mod;
@@ -492,6 +492,7 @@ int nm_eval(nm_ctx *c, double *U, double *W, double *f)
 {
     if (!c || !U || !W) return fail(c, NM_ERR_ARG, "nm_eval: null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    ++c->launch_id;
     KParams p;
     fill_params(c, p);
     p.eval_only = 1; p.tape = nullptr;

@@ -42,8 +42,9 @@ struct KParams {
     double *aux_g;                 // global spill of the saved copies (large N): [slot][AUX_DOUBLES(N)]
     unsigned long long *prof;      // diagnostic build only
     int cus;                       // workgroups (CUs) cooperating on one replica
+    int dbg;                       // NM_DBG: timing experiments only (skips work, results are wrong)
     double *xbuf;                  // [slot][2][XBUF_DOUBLES]: force slices + partial sums exchanged inside a cluster
-    int *arrive;                   // [slot] arrival counter of the cluster (zeroed before every launch)
+    uint32_t launch_id;            // distinguishes the granules of successive launches
 };
 
 // ------------------------------------------------------------------------------------------ Philox4x32-10
@@ -95,6 +96,23 @@ __device__ __forceinline__ double uniform(double v)
 }
 
 // ------------------------------------------------------------------------------------------ reductions
+// Workgroup-wide OR with one barrier: a ballot per wave, one LDS word per wave (HIP's __syncthreads_or funnels all
+// 512 threads through LDS atomics: ~4k cycles per call in this kernel).  Same two-halves trick as block_sum.
+template <int NW, int NVMAX>
+__device__ __forceinline__ bool block_any(bool flag, double *red, int &parity)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int *r = (int *)(red + parity * (NW * NVMAX));
+    const unsigned long long m = __ballot(flag);
+    if (lane == 0) r[wv] = (m != 0ull) ? 1 : 0;
+    __syncthreads();
+    int any = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) any |= r[w];
+    parity ^= 1;
+    return __builtin_amdgcn_readfirstlane(any) != 0;
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll

@@ -52,7 +52,8 @@ struct Cfg {
     static constexpr size_t AUX_DOUBLES = SAVE_LDS ? 0 : (size_t)9 * NMAX + ((size_t)3 * NMAX * 3 + 7) / 8;
     static constexpr size_t NBR_G_ELEMS = LIST_LDS ? 0 : (size_t)MAXNB * NMAX; // per-slot global list
     static constexpr int QMAX = 8;                                               // most workgroups per replica
-    static constexpr size_t XBUF_DOUBLES = (size_t)3 * NMAX + 4 * QMAX;          // one exchange buffer (there are two per slot)
+    static constexpr size_t XBUF_GRANULES = (size_t)3 * NMAX + 4 * QMAX;         // forces by component + per-workgroup partials
+    static constexpr size_t XBUF_DOUBLES = 2 * XBUF_GRANULES;                    // one exchange buffer (there are two per slot)
 };
 
 template <class C>
@@ -65,7 +66,6 @@ struct Replica {
     // cluster: Q workgroups (one per CU) run the same replica redundantly and split only the pair work by atom range
     const int Q, q, a0, a1;
     double *xb;
-    int *arrive;
     int gen = 0;
     double *px, *py, *pz, *vx, *vy, *vz, *fx, *fy, *fz;
     double *sx, *sy, *sz, *svx, *svy, *svz, *x0, *y0, *z0;
@@ -89,7 +89,6 @@ struct Replica {
           a1((p_.N * (q_ + 1)) / p_.cus)
     {
         xb = p.xbuf ? p.xbuf + (size_t)slot * 2 * C::XBUF_DOUBLES : nullptr;
-        arrive = p.arrive ? p.arrive + slot : nullptr;
         px = (double *)(smem + C::OFF_POS); py = px + NMAX; pz = py + NMAX;
         vx = (double *)(smem + C::OFF_VEL); vy = vx + NMAX; vz = vy + NMAX;
         fx = (double *)(smem + C::OFF_FRC); fy = fx + NMAX; fz = fy + NMAX;
@@ -247,7 +246,7 @@ struct Replica {
         L0 = L;
         list_ok = true;
         st_rebuilds += 1.0;
-        if (__syncthreads_or(ovf)) status |= ST_LIST_OVERFLOW;
+        if (block_any<NW, NVMAX>(ovf != 0, red, parity)) status |= ST_LIST_OVERFLOW;
     }
 
     // 1/r2 by v_rcp_f64 + two Newton steps (about 1 ulp) instead of the 12-instruction IEEE division sequence
@@ -308,69 +307,94 @@ struct Replica {
             }
             if (i < a1 && sub == 0) {
                 fx[i] = ax; fy[i] = ay; fz[i] = az; eacc += e; wacc += w; nacc += np;
-                if (Q > 1) { // publish this atom's force to the other workgroups of the cluster (write-through store)
-                    __hip_atomic_store(xg + i, ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(xg + NMAX + i, ay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(xg + 2 * NMAX + i, az, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (Q > 1) { // publish this atom's force to the other workgroups of the cluster
+                    const unsigned long long mg = magic();
+                    put_granule(xg + 2 * (size_t)i, ax, mg);
+                    put_granule(xg + 2 * (size_t)(NMAX + i), ay, mg);
+                    put_granule(xg + 2 * (size_t)(2 * NMAX + i), az, mg);
                 }
             }
         }
     }
 
     // ------------------------------------------------------------------ cluster hand-off (Q workgroups per replica)
-    // Every workgroup has just stored the forces of its own atoms (and, below, its partial sums and status bits) with
-    // write-through (sc1) stores into exchange buffer gen&1.  Protocol (MI355X guide, Guideline 16 / hand-off table row 1):
-    // every storing wave drains vmcnt, workgroup barrier, ONE lane adds to the cluster's arrival counter (agent scope),
-    // ONE lane polls it with sc1 loads, workgroup barrier, then every load of the handed-off bytes is an sc1 load.
-    // Two buffers alternate, and a workgroup can only run one evaluation ahead of the slowest (it needs everybody's
-    // arrival), so a buffer is never overwritten while someone still reads it.  The spin is bounded: a cluster that is
-    // not co-resident reports ST_SYNC_TIMEOUT instead of hanging.
+    // Data-tagged granules (MI355X guide, hand-off price list "handoff-1to1"): every exchanged double travels as ONE
+    // 16-byte write-through (sc1) store {bits, bits ^ magic}, magic = f(launch, evaluation).  A reader polls the granule
+    // itself with sc1 loads until the two words agree with the magic of the evaluation it is in: no flag, no counter, no
+    // fence, one memory round trip.  A torn or stale granule fails the check (probability 2^-64 otherwise) and is re-read.
+    // Two buffers alternate; a workgroup can only run one evaluation ahead of the slowest one (it needs everybody's
+    // forces of evaluation g to finish g), so buffer g&1 is never overwritten while someone still reads it.  Spins are
+    // bounded: a cluster that is not co-resident reports ST_SYNC_TIMEOUT instead of hanging.
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    __device__ __forceinline__ unsigned long long magic() const
+    {
+        return ((unsigned long long)p.launch_id << 32 | (unsigned long long)(uint32_t)(gen + 1)) * 0x9E3779B97F4A7C15ull | 1ull;
+    }
+    __device__ __forceinline__ void put_granule(double *g, double v, unsigned long long mg)
+    {
+        u64x2 w;
+        w.x = (unsigned long long)__double_as_longlong(v);
+        w.y = w.x ^ mg;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(g), "v"(w) : "memory");
+    }
+    // up to three granules per call, issued back to back and waited for once
+    template <int K>
+    __device__ __forceinline__ bool get_granules(double *const (&g)[K], unsigned long long mg, double (&out)[K], int &timeout)
+    {
+        const unsigned long long t0 = wall_clock64(); // 100 MHz
+        for (;;) {
+            u64x2 w[K];
+            if constexpr (K == 3)
+                asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\t"
+                             "global_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]) : "v"(g[0]), "v"(g[1]), "v"(g[2]) : "memory");
+            else
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w[0]) : "v"(g[0]) : "memory");
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < K; ++k) ok = ok && ((w[k].x ^ w[k].y) == mg);
+            if (ok) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) out[k] = __longlong_as_double((long long)w[k].x);
+                return true;
+            }
+            if (wall_clock64() - t0 > 200000000ull) { timeout = 1; return false; } // 2 s
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+
     __device__ void cluster_exchange(bool want_e, double (&s)[3])
     {
         double *xg = xb + (size_t)(gen & 1) * C::XBUF_DOUBLES;
-        if (tid == 0) {
-            double *ps = xg + 3 * NMAX + 4 * q;
-            __hip_atomic_store(ps + 0, s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(ps + 1, s[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(ps + 2, s[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(ps + 3, (double)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long mg = magic();
+        if (tid < 4) { // this workgroup's partial sums and status bits
+            const double v = tid == 0 ? s[0] : tid == 1 ? s[1] : tid == 2 ? s[2] : (double)status;
+            put_granule(xg + 2 * (size_t)(3 * NMAX + 4 * q + tid), v, mg);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
         int timeout = 0;
-        if (tid == 0) {
-            const int target = Q * (gen + 1);
-            __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long t0 = wall_clock64(); // 100 MHz
-            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(1);
-                if (wall_clock64() - t0 > 200000000ull) { timeout = 1; break; } // 2 s
-            }
+        // forces of the atoms the other workgroups own: one thread per atom, three granules in flight
+        const int nother = N - (a1 - a0);
+        for (int o = tid; o < nother; o += BLOCK) {
+            const int i = o < a0 ? o : o + (a1 - a0);
+            double *const g3[3] = { xg + 2 * (size_t)i, xg + 2 * (size_t)(NMAX + i), xg + 2 * (size_t)(2 * NMAX + i) };
+            double f3[3];
+            if (get_granules<3>(g3, mg, f3, timeout)) { fx[i] = f3[0]; fy[i] = f3[1]; fz[i] = f3[2]; }
         }
-        if (__syncthreads_or(timeout)) { status |= ST_SYNC_TIMEOUT; ++gen; return; }
-        // forces of the atoms the other workgroups own
-        for (int i = tid; i < N; i += BLOCK)
-            if (i < a0 || i >= a1) {
-                fx[i] = __hip_atomic_load(xg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                fy[i] = __hip_atomic_load(xg + NMAX + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                fz[i] = __hip_atomic_load(xg + 2 * NMAX + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        // partial sums and status bits in workgroup order: identical bits in every workgroup of the cluster
+        // partial sums and status bits in workgroup order (every thread reads them: identical bits everywhere)
         double t0s = 0.0, t1s = 0.0, t2s = 0.0;
         int st = 0;
         for (int r = 0; r < Q; ++r) {
-            const double *ps = xg + 3 * NMAX + 4 * r;
-            if (want_e) {
-                t0s += __hip_atomic_load(ps + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                t1s += __hip_atomic_load(ps + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                t2s += __hip_atomic_load(ps + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            st |= (int)__hip_atomic_load(ps + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double *const gs[3] = { xg + 2 * (size_t)(3 * NMAX + 4 * r), xg + 2 * (size_t)(3 * NMAX + 4 * r + 1),
+                                    xg + 2 * (size_t)(3 * NMAX + 4 * r + 2) };
+            double *const gt[1] = { xg + 2 * (size_t)(3 * NMAX + 4 * r + 3) };
+            double v3[3] = { 0.0, 0.0, 0.0 }, v1[1] = { 0.0 };
+            if (want_e && get_granules<3>(gs, mg, v3, timeout)) { t0s += v3[0]; t1s += v3[1]; t2s += v3[2]; }
+            if (get_granules<1>(gt, mg, v1, timeout)) st |= (int)v1[0];
         }
+        ++gen;
+        if (block_any<NW, NVMAX>(timeout != 0, red, parity)) { status |= ST_SYNC_TIMEOUT; return; } // also publishes f to the block
         s[0] = uniform(t0s); s[1] = uniform(t1s); s[2] = uniform(t2s);
         status |= __builtin_amdgcn_readfirstlane(st);
-        ++gen;
-        __syncthreads();
     }
 
     // ------------------------------------------------------------------ lj/cut 2.5 energy, forces, virial
@@ -385,7 +409,7 @@ struct Replica {
         bool need = !list_ok;
         const double invL = 1.0 / L;
         PROF_BEGIN();
-        if (!need) {
+        if (!need && !(p.dbg & 4)) {
             // the list built at (x0, L0) still covers every pair within rc of the affinely rescaled reference if
             // max_i |x_i - (L/L0) x0_i| <= ((L/L0)(rc+skin) - rc)/2
             const double sc = L / L0;
@@ -396,7 +420,7 @@ struct Replica {
                 dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
                 if (dx * dx + dy * dy + dz * dz > thr2) bad = 1;
             }
-            need = __syncthreads_or(bad);
+            need = block_any<NW, NVMAX>(bad != 0, red, parity);
         }
         PROF_END(1);
         PROF_BEGIN();
@@ -405,15 +429,20 @@ struct Replica {
 
         double eacc = 0.0, wacc = 0.0, nacc = 0.0;
         PROF_BEGIN();
-        if (want_e) pair_loop<true>(invL, eacc, wacc, nacc);
+        if (p.dbg & 16) { }
+        else if (want_e) pair_loop<true>(invL, eacc, wacc, nacc);
         else pair_loop<false>(invL, eacc, wacc, nacc);
         PROF_END(3);
         PROF_BEGIN();
         st_evals += 1.0;
         double s[3] = { eacc, wacc, nacc };
         if (want_e) block_sum<3, NW, NVMAX>(s, red, parity); // over this workgroup's atoms
-        if (Q > 1) cluster_exchange(want_e, s);
-        else if (!want_e) __syncthreads();
+        PROF_END(4);
+        PROF_BEGIN();
+        if (Q > 1 && !(p.dbg & 8)) cluster_exchange(want_e, s);
+        else if (!want_e || Q > 1) __syncthreads();
+        PROF_END(14);
+        PROF_BEGIN();
         if (want_e) {
             U = 0.5 * s[0]; W = 0.5 * s[1];
             st_eevals += 1.0; st_pairs += 0.5 * s[2];
@@ -750,9 +779,8 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
             } else { // hamiltonian_mc, remcmc:598-608
                 nth += 1.0;
                 const uint32_t tag = R.draw_tag((uint32_t)m);
-                R.velocity_create(q6(t), tag);
-                R.zero_linear();
-                R.zero_angular();
+                if (!(p.dbg & 2)) R.velocity_create(q6(t), tag);
+                if (!(p.dbg & 1)) { R.zero_linear(); R.zero_angular(); }
                 c_h = uniform(q6(dt)); // timestep %f
                 c_dtfm = 0.5 * c_h * p.ftm2v / p.mass;
                 R.wrap(); // run 0

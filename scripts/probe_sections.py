@@ -8,7 +8,7 @@ import neuralmelting_amd as nm
 from neuralmelting_amd import lattice, _lib
 
 NAMES = ['eval:entry barrier', 'eval:list check', 'eval:rebuild', 'eval:pair loop', 'eval:reduce/barrier',
-         'post:init', 'post:bulk', 'post:vmc', 'post:hmc start', 'post:hmc step', 'pre:bulk', 'pre:vmc', 'pre:hmc', 'iter pmc', '-', '-']
+         'post:init', 'post:bulk', 'post:vmc', 'post:hmc start', 'post:hmc step', 'pre:bulk', 'pre:vmc', 'pre:hmc', 'iter pmc', 'eval:cluster exchange', '-']
 
 def main(sz=4, rows=8, tn=8, mod=128, cycles=3, warm=6):
     P = np.linspace(1, 8, rows, dtype=np.float32); T = np.linspace(.25, 2.5, tn, dtype=np.float32)
