@@ -131,7 +131,7 @@ def main():
             'fp64': {'achieved': tf, 'peak': FP64_VEC_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tf / FP64_VEC_PEAK_TF,
                      'evals_per_sweep': evals / (ns * args.mod * args.steps), 'mean_pairs_per_eval': mean_pairs,
                      'flop_per_pair': FLOP_PER_PAIR, 'list_rebuilds_per_sweep': st[:, 1].sum() / (ns * args.mod * args.steps),
-                     'cus_occupied': ns, 'cus_total': 256},
+                     'cus_per_replica': eng.cus_per_replica, 'cus_occupied': ns * eng.cus_per_replica, 'cus_total': 256},
         }
         if not args.no_cpu:
             out['cpu_baseline'] = cpu_baseline(eng, natoms, args, T, P, row0)
@@ -155,6 +155,7 @@ def cpu_baseline(eng, natoms, args, T, P, row0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, ns)  # one replica per thread: more threads than replicas would idle
     t0 = time.perf_counter()
     for c in range(args.cpu_cycles):
         out = O.run_blocks(x, v, box, d, et, et, pf, natoms=natoms, mod=args.mod, nstps=8, bulk=True, ppos=0.125,

@@ -67,6 +67,7 @@ int nm_destroy(nm_ctx *ctx);
 const char *nm_last_error(const nm_ctx *ctx);  /* ctx may be NULL: error of the last failed nm_create */
 int nm_nslots(const nm_ctx *ctx);              /* nrows*nt replicas held by this context               */
 int nm_natoms(const nm_ctx *ctx);
+int nm_cus_per_replica(const nm_ctx *ctx);     /* workgroups (CUs) cooperating on one replica: 1, 2, 4 ...  */
 
 /* thermodynamic constants per local slot: et = k_B T, pf = P/(k_B T) (init_constant, remcmc:114-132) */
 int nm_get_const(const nm_ctx *ctx, double *et, double *pf);

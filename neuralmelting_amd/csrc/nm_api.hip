@@ -153,6 +153,7 @@ extern "C" {
 const char *nm_last_error(const nm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 int nm_nslots(const nm_ctx *ctx) { return ctx ? ctx->nslots : NM_ERR_ARG; }
 int nm_natoms(const nm_ctx *ctx) { return ctx ? ctx->N : NM_ERR_ARG; }
+int nm_cus_per_replica(const nm_ctx *ctx) { return ctx ? ctx->cus : NM_ERR_ARG; }
 
 int nm_create(const nm_config *cfg, nm_ctx **out)
 {

@@ -48,6 +48,7 @@ class Engine:
         self.h = h
         self.natoms = int(natoms)
         self.nslots = self.lib.nm_nslots(self.h)
+        self.cus_per_replica = self.lib.nm_cus_per_replica(self.h)
 
     # -- plumbing
     def _chk(self, rc):
