@@ -14,7 +14,7 @@
 
 namespace nm {
 
-constexpr int NVMAX = 10; // widest block reduction (angular momentum 3 + inertia 6)
+constexpr int NVMAX = 12; // widest block reduction (momentum 3 + angular momentum 3 + inertia 6)
 
 // Diagnostic build only (-DNM_PROF, never the shipped library): shader-clock stamps per section, summed by lane 0
 // of each workgroup into KParams::prof[slot][NM_PROF_SLOTS].
@@ -335,7 +335,9 @@ struct Replica {
         u64x2 w;
         w.x = (unsigned long long)__double_as_longlong(v);
         w.y = w.x ^ mg;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(g), "v"(w) : "memory");
+        // hipcc adds no wait states for an asm statement: a VMEM store of more than 8 bytes needs one before its data
+        // registers may be overwritten (gfx9 hazard), hence the s_nop inside the string
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(g), "v"(w) : "memory");
     }
     // up to three granules per call, issued back to back and waited for once
     template <int K>
@@ -402,14 +404,17 @@ struct Replica {
     // Full (both-direction) list: thread group (i, sub) owns f_i, no scatter, no atomics, fixed summation order.
     __device__ void eval(bool want_e)
     {
-        PROF_BEGIN();
-        __syncthreads(); // positions written by their owners are visible; previous readers are done
-        PROF_END(0);
-        if (!(L >= 2.0 * p.rc)) { status |= ST_BOX_TOO_SMALL; return; } // minimum-image limit
+        if (!(L >= 2.0 * p.rc)) { status |= ST_BOX_TOO_SMALL; __syncthreads(); return; } // minimum-image limit
         bool need = !list_ok;
         const double invL = 1.0 / L;
         PROF_BEGIN();
-        if (!need && !(p.dbg & 4)) {
+        // The validity check reads only a thread's own atoms (written by itself) and x0 (settled since the last rebuild), so
+        // it needs no barrier before it; its own block-wide OR is the barrier that publishes the new positions to everybody.
+#ifdef NM_ENTRY_BARRIER
+        __syncthreads();
+#endif
+        if (need || (p.dbg & 4)) __syncthreads();
+        else {
             // the list built at (x0, L0) still covers every pair within rc of the affinely rescaled reference if
             // max_i |x_i - (L/L0) x0_i| <= ((L/L0)(rc+skin) - rc)/2
             const double sc = L / L0;
@@ -453,78 +458,79 @@ struct Replica {
     }
 
     // ------------------------------------------------------------------ velocity commands (remcmc:604-606)
-    __device__ void zero_linear()
-    {
-        double s[3] = { 0.0, 0.0, 0.0 };
-        for (int i = tid; i < N; i += BLOCK) { s[0] += p.mass * vx[i]; s[1] += p.mass * vy[i]; s[2] += p.mass * vz[i]; }
-        block_sum<3, NW, NVMAX>(s, red, parity);
-        const double mt = p.mass * N;
-        const double cx = s[0] / mt, cy = s[1] / mt, cz = s[2] / mt;
-        for (int i = tid; i < N; i += BLOCK) { vx[i] -= cx; vy[i] -= cy; vz[i] -= cz; }
-    }
-    // velocity all create t seed dist gaussian: gaussians/sqrt(m) per atom id, COM momentum removed,
-    // rescaled to exactly t with dof = 3N-3 (LAMMPS velocity.cpp create(), defaults mom yes rot no)
-    __device__ void velocity_create(double t, uint32_t tag)
+    // velocity all create t seed dist gaussian   (gaussians/sqrt(m) per atom id, COM momentum removed, rescaled to exactly
+    //                                             t with dof = 3N-3: LAMMPS velocity.cpp create(), defaults mom yes rot no)
+    // velocity all zero linear                   (again removes the COM momentum, now round-off only)
+    // velocity all zero angular                  (omega = I^-1 L about the centre of mass of the unwrapped coordinates)
+    // in three block reductions: {sum m v, sum m X}, {sum m v^2}, {sum m v, L, I}.  L is accumulated with the velocities
+    // before the second COM subtraction: the difference is (sum m d) x v_cm with sum m d = 0 about the centre of mass.
+    __device__ void hmc_velocities(double t, uint32_t tag)
     {
         const double twopi = 6.283185307179586476925286766559;
-        const double fac = 1.0 / sqrt(p.mass);
+        const double m = p.mass, fac = 1.0 / sqrt(m), mt = m * N;
+        double a[6] = { 0, 0, 0, 0, 0, 0 };
         for (int i = tid; i < N; i += BLOCK) {
-            uint32_t o[4], q[4];
-            philox4x32_10((uint32_t)i, S_VEL_A, tag, p.step, p.seed, (uint32_t)gslot, o);
-            philox4x32_10((uint32_t)i, S_VEL_B, tag, p.step, p.seed, (uint32_t)gslot, q);
-            const double u1 = u01(o[0], o[1]), u2 = u01(o[2], o[3]), u3 = u01(q[0], q[1]), u4 = u01(q[2], q[3]);
-            const double r1 = sqrt(-2.0 * log(1.0 - u1)), r2 = sqrt(-2.0 * log(1.0 - u3));
-            vx[i] = r1 * cos(twopi * u2) * fac;
-            vy[i] = r1 * sin(twopi * u2) * fac;
-            vz[i] = r2 * cos(twopi * u4) * fac;
+            double nx = vx[i], ny = vy[i], nz = vz[i];
+            if (!(p.dbg & 2)) {
+                uint32_t o[4], q[4];
+                philox4x32_10((uint32_t)i, S_VEL_A, tag, p.step, p.seed, (uint32_t)gslot, o);
+                philox4x32_10((uint32_t)i, S_VEL_B, tag, p.step, p.seed, (uint32_t)gslot, q);
+                const double u1 = u01(o[0], o[1]), u2 = u01(o[2], o[3]), u3 = u01(q[0], q[1]), u4 = u01(q[2], q[3]);
+                const double r1 = sqrt(-2.0 * log(1.0 - u1)), r2 = sqrt(-2.0 * log(1.0 - u3));
+                nx = r1 * cos(twopi * u2) * fac; ny = r1 * sin(twopi * u2) * fac; nz = r2 * cos(twopi * u4) * fac;
+            }
+            vx[i] = nx; vy[i] = ny; vz[i] = nz;
+            a[0] += m * nx; a[1] += m * ny; a[2] += m * nz;
+            a[3] += m * (px[i] + im[3 * i] * L); a[4] += m * (py[i] + im[3 * i + 1] * L); a[5] += m * (pz[i] + im[3 * i + 2] * L);
         }
-        zero_linear();
+        block_sum<6, NW, NVMAX>(a, red, parity);
+        const double c0 = a[0] / mt, c1 = a[1] / mt, c2 = a[2] / mt;   // COM velocity
+        const double cx = a[3] / mt, cy = a[4] / mt, cz = a[5] / mt;   // centre of mass (unwrapped)
+        double s2[1] = { 0.0 };
+        for (int i = tid; i < N; i += BLOCK) {
+            const double ax = vx[i] - c0, ay = vy[i] - c1, az = vz[i] - c2;
+            vx[i] = ax; vy[i] = ay; vz[i] = az;
+            s2[0] += m * (ax * ax + ay * ay + az * az);
+        }
+        block_sum<1, NW, NVMAX>(s2, red, parity);
         const double dof = 3.0 * N - 3.0;
-        const double tcur = sum_mv2() * p.mvv2e / (dof * p.kB);
+        const double tcur = s2[0] * p.mvv2e / (dof * p.kB);
         const double sc = sqrt(t / tcur);
-        for (int i = tid; i < N; i += BLOCK) { vx[i] *= sc; vy[i] *= sc; vz[i] *= sc; }
-    }
-    // velocity all zero angular: omega = I^-1 L about the centre of mass of the unwrapped coordinates
-    __device__ void zero_angular()
-    {
-        const double m = p.mass;
-        double c[3] = { 0.0, 0.0, 0.0 };
+        double s[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // sum m v (3), L (3), I00 I11 I22 I01 I12 I02
         for (int i = tid; i < N; i += BLOCK) {
-            c[0] += m * (px[i] + im[3 * i] * L); c[1] += m * (py[i] + im[3 * i + 1] * L); c[2] += m * (pz[i] + im[3 * i + 2] * L);
-        }
-        block_sum<3, NW, NVMAX>(c, red, parity);
-        const double mt = m * N;
-        const double cx = c[0] / mt, cy = c[1] / mt, cz = c[2] / mt;
-        double s[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // L(3), I00 I11 I22 I01 I12 I02
-        for (int i = tid; i < N; i += BLOCK) {
+            const double ax = vx[i] * sc, ay = vy[i] * sc, az = vz[i] * sc;
+            vx[i] = ax; vy[i] = ay; vz[i] = az;
             const double dx = px[i] + im[3 * i] * L - cx, dy = py[i] + im[3 * i + 1] * L - cy, dz = pz[i] + im[3 * i + 2] * L - cz;
-            s[0] += m * (dy * vz[i] - dz * vy[i]);
-            s[1] += m * (dz * vx[i] - dx * vz[i]);
-            s[2] += m * (dx * vy[i] - dy * vx[i]);
-            s[3] += m * (dy * dy + dz * dz);
-            s[4] += m * (dx * dx + dz * dz);
-            s[5] += m * (dx * dx + dy * dy);
-            s[6] -= m * dx * dy;
-            s[7] -= m * dy * dz;
-            s[8] -= m * dx * dz;
+            s[0] += m * ax; s[1] += m * ay; s[2] += m * az;
+            s[3] += m * (dy * az - dz * ay);
+            s[4] += m * (dz * ax - dx * az);
+            s[5] += m * (dx * ay - dy * ax);
+            s[6] += m * (dy * dy + dz * dz);
+            s[7] += m * (dx * dx + dz * dz);
+            s[8] += m * (dx * dx + dy * dy);
+            s[9] -= m * dx * dy;
+            s[10] -= m * dy * dz;
+            s[11] -= m * dx * dz;
         }
-        block_sum<9, NW, NVMAX>(s, red, parity);
-        const double I00 = s[3], I11 = s[4], I22 = s[5], I01 = s[6], I12 = s[7], I02 = s[8];
+        if (p.dbg & 1) return;
+        block_sum<12, NW, NVMAX>(s, red, parity);
+        const double e0 = s[0] / mt, e1 = s[1] / mt, e2 = s[2] / mt;
+        const double I00 = s[6], I11 = s[7], I22 = s[8], I01 = s[9], I12 = s[10], I02 = s[11];
         const double det = I00 * I11 * I22 + I01 * I12 * I02 + I02 * I01 * I12 - I00 * I12 * I12 - I01 * I01 * I22 - I02 * I11 * I02;
         double w0 = 0.0, w1 = 0.0, w2 = 0.0;
         if (det > 0.0) {
             const double i00 = I11 * I22 - I12 * I12, i01 = -(I01 * I22 - I02 * I12), i02 = I01 * I12 - I02 * I11;
             const double i10 = -(I01 * I22 - I12 * I02), i11 = I00 * I22 - I02 * I02, i12 = -(I00 * I12 - I02 * I01);
             const double i20 = I01 * I12 - I11 * I02, i21 = -(I00 * I12 - I01 * I02), i22 = I00 * I11 - I01 * I01;
-            w0 = (i00 * s[0] + i01 * s[1] + i02 * s[2]) / det;
-            w1 = (i10 * s[0] + i11 * s[1] + i12 * s[2]) / det;
-            w2 = (i20 * s[0] + i21 * s[1] + i22 * s[2]) / det;
+            w0 = (i00 * s[3] + i01 * s[4] + i02 * s[5]) / det;
+            w1 = (i10 * s[3] + i11 * s[4] + i12 * s[5]) / det;
+            w2 = (i20 * s[3] + i21 * s[4] + i22 * s[5]) / det;
         }
         for (int i = tid; i < N; i += BLOCK) {
             const double dx = px[i] + im[3 * i] * L - cx, dy = py[i] + im[3 * i + 1] * L - cy, dz = pz[i] + im[3 * i + 2] * L - cz;
-            vx[i] -= w1 * dz - w2 * dy;
-            vy[i] -= w2 * dx - w0 * dz;
-            vz[i] -= w0 * dy - w1 * dx;
+            vx[i] = (vx[i] - e0) - (w1 * dz - w2 * dy);
+            vy[i] = (vy[i] - e1) - (w2 * dx - w0 * dz);
+            vz[i] = (vz[i] - e2) - (w0 * dy - w1 * dx);
         }
     }
 
@@ -700,18 +706,21 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
             PROF_END(5 + PH_HMC_START);
             continue;
         } else { // PH_HMC_STEP: forces at the new positions are in
-            for (int i = tid; i < N; i += BLOCK) { // final_integrate
-                R.vx[i] += c_dtfm * R.fx[i]; R.vy[i] += c_dtfm * R.fy[i]; R.vz[i] += c_dtfm * R.fz[i];
-            }
             ++hstep;
             if (hstep < p.nstps) {
-                for (int i = tid; i < N; i += BLOCK) {
-                    R.vx[i] += c_dtfm * R.fx[i]; R.vy[i] += c_dtfm * R.fy[i]; R.vz[i] += c_dtfm * R.fz[i];
-                    R.px[i] += c_h * R.vx[i]; R.py[i] += c_h * R.vy[i]; R.pz[i] += c_h * R.vz[i];
+                for (int i = tid; i < N; i += BLOCK) { // final_integrate of this step + initial_integrate of the next, same arithmetic
+                    const double gx = R.fx[i], gy = R.fy[i], gz = R.fz[i];
+                    double ux = __builtin_fma(c_dtfm, gx, R.vx[i]), uy = __builtin_fma(c_dtfm, gy, R.vy[i]), uz = __builtin_fma(c_dtfm, gz, R.vz[i]);
+                    ux = __builtin_fma(c_dtfm, gx, ux); uy = __builtin_fma(c_dtfm, gy, uy); uz = __builtin_fma(c_dtfm, gz, uz);
+                    R.vx[i] = ux; R.vy[i] = uy; R.vz[i] = uz;
+                    R.px[i] += c_h * ux; R.py[i] += c_h * uy; R.pz[i] += c_h * uz;
                 }
                 want_e = (hstep == p.nstps - 1);
                 PROF_END(5 + PH_HMC_STEP);
                 continue;
+            }
+            for (int i = tid; i < N; i += BLOCK) { // final_integrate of the last step
+                R.vx[i] += c_dtfm * R.fx[i]; R.vy[i] += c_dtfm * R.fy[i]; R.vz[i] += c_dtfm * R.fz[i];
             }
             const double etotnew = R.U / et + 0.5 * p.mvv2e * R.sum_mv2() / et; // remcmc:618-622
             crit = etotnew - c_pe;
@@ -779,8 +788,7 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
             } else { // hamiltonian_mc, remcmc:598-608
                 nth += 1.0;
                 const uint32_t tag = R.draw_tag((uint32_t)m);
-                if (!(p.dbg & 2)) R.velocity_create(q6(t), tag);
-                if (!(p.dbg & 1)) { R.zero_linear(); R.zero_angular(); }
+                R.hmc_velocities(q6(t), tag);
                 c_h = uniform(q6(dt)); // timestep %f
                 c_dtfm = 0.5 * c_h * p.ftm2v / p.mass;
                 R.wrap(); // run 0
