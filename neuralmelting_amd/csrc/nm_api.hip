@@ -24,6 +24,9 @@ typedef Cfg<NM_SMALL_BLOCK, 2 * NM_SMALL_TPA, 256, 160, unsigned char, true, tru
 typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 160, unsigned char, true, true> CfgSmallQ4;
 typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 160, unsigned char, true, true> CfgSmall;     // N <= 256: everything incl. the byte list in LDS
 typedef Cfg<512, 1, 864, 160, unsigned short, false, true> CfgMid;     // N <= 864: list in HBM/L2, saved copies in LDS
+typedef Cfg<512, 1, 864, 160, unsigned short, false, true> CfgMidQ2;   // cluster variants: own atoms 432 / 216 / 108
+typedef Cfg<512, 2, 864, 160, unsigned short, false, true> CfgMidQ4;
+typedef Cfg<512, 4, 864, 160, unsigned short, false, true> CfgMidQ8;
 typedef Cfg<512, 1, 2048, 160, unsigned short, false, false> CfgLarge; // N <= 2048: saved copies spill to HBM as well
 
 thread_local std::string g_create_error;
@@ -111,7 +114,7 @@ hipError_t launch_kind(const nm_ctx *c, const KParams &p)
 {
     switch (c->kind) {
     case 0: return c->cus == 4 ? launch_block<CfgSmallQ4>(c, p) : c->cus == 2 ? launch_block<CfgSmallQ2>(c, p) : launch_block<CfgSmall>(c, p);
-    case 1: return launch_block<CfgMid>(c, p);
+    case 1: return c->cus == 8 ? launch_block<CfgMidQ8>(c, p) : c->cus == 4 ? launch_block<CfgMidQ4>(c, p) : launch_block<CfgMid>(c, p);
     default: return launch_block<CfgLarge>(c, p);
     }
 }
@@ -217,14 +220,15 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     // Workgroups per replica.  A cluster spins on its peers, so every workgroup of the grid must be resident at once: the
     // small kernel admits one workgroup per CU (LDS + registers), so nslots*Q must not exceed the CU count (with a margin).
     c->cus = 1; c->d_xbuf = nullptr; c->launch_id = 0;
-    if (c->kind == 0) {
+    {
         hipDeviceProp_t prop;
         CHK(hipGetDeviceProperties(&prop, cfg->device));
         const int cu = prop.multiProcessorCount;
-        int want = 4;
+        int want = 8;
         if (const char *e = std::getenv("NM_CUS_PER_REPLICA")) want = std::atoi(e);
-        for (int qq : { 4, 2 })
-            if (want >= qq && c->nslots * qq <= cu) { c->cus = qq; break; }
+        const int maxq = c->kind == 0 ? 4 : c->kind == 1 ? 8 : 2; // own-atom ranges the instantiated thread mappings cover
+        for (int qq : { 8, 4, 2 })
+            if (qq <= maxq && want >= qq && c->nslots * qq <= cu) { c->cus = qq; break; }
     }
     const size_t ns = c->nslots, n3 = (size_t)3 * c->N;
     CHK(dalloc(&c->d_x, ns * n3)); CHK(dalloc(&c->d_v, ns * n3));
@@ -242,8 +246,9 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
 #endif
     c->d_tape = nullptr; c->d_tape_off = nullptr; c->d_trace = nullptr; c->d_nbr = nullptr; c->d_aux = nullptr;
     if (nbr_elems) CHK(hipMalloc(&c->d_nbr, ns * nbr_elems * sizeof(unsigned short)));
-    if (c->aux_doubles) CHK(dalloc(&c->d_aux, ns * c->aux_doubles));
-    if (c->cus > 1) { CHK(dalloc(&c->d_xbuf, ns * 2 * CfgSmall::XBUF_DOUBLES)); CHK(hipMemset(c->d_xbuf, 0, ns * 2 * CfgSmall::XBUF_DOUBLES * sizeof(double))); }
+    if (c->aux_doubles) CHK(dalloc(&c->d_aux, ns * c->cus * c->aux_doubles));
+    const size_t xbd = c->kind == 0 ? CfgSmall::XBUF_DOUBLES : c->kind == 1 ? CfgMid::XBUF_DOUBLES : CfgLarge::XBUF_DOUBLES;
+    if (c->cus > 1) { CHK(dalloc(&c->d_xbuf, ns * 2 * xbd)); CHK(hipMemset(c->d_xbuf, 0, ns * 2 * xbd * sizeof(double))); }
     CHK(hipMemset(c->d_x, 0, ns * n3 * sizeof(double))); CHK(hipMemset(c->d_v, 0, ns * n3 * sizeof(double)));
     CHK(hipMemset(c->d_box, 0, ns * sizeof(double))); CHK(hipMemset(c->d_steps, 0, ns * 3 * sizeof(double)));
     CHK(hipMemset(c->d_therm, 0, ns * 5 * sizeof(double))); CHK(hipMemset(c->d_count, 0, ns * 6 * sizeof(double)));
@@ -261,7 +266,11 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
         CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallQ2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
         CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallQ4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
     }
-    else if (c->kind == 1) CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgMid>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+    else if (c->kind == 1) {
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgMid>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgMidQ4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgMidQ8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+    }
     else CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgLarge>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
     c->ev.resize(32);
     for (auto &e : c->ev) { CHK(hipEventCreate(&e.a)); CHK(hipEventCreate(&e.b)); e.used = false; }

@@ -99,7 +99,7 @@ struct Replica {
             im = (short *)(smem + C::OFF_IMG);
             wn = (signed char *)(smem + C::OFF_WN);
         } else {
-            double *a = p.aux_g + (size_t)slot * C::AUX_DOUBLES;
+            double *a = p.aux_g + ((size_t)slot * p.cus + q_) * C::AUX_DOUBLES; // one spill area per workgroup
             sx = a; svx = a + 3 * (size_t)NMAX; x0 = a + 6 * (size_t)NMAX;
             im = (short *)(a + 9 * (size_t)NMAX);
             wn = (signed char *)(im + 3 * (size_t)NMAX);
