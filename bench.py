@@ -45,7 +45,7 @@ def main():
                              % (args.gpus, args.gpus))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:  # under torch.distributed.run: one rank per GPU over RCCL (also at N=1)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
@@ -123,7 +123,7 @@ def main():
                                    'HMC 0.75 x %d steps, outputs off' % (args.sz, natoms, args.rows, args.tn, args.mod, 8),
                        'replicas_per_gpu': ns, 'sweeps_per_step': world * ns * args.mod, 'parallelism': 'rows/gpu'},
             'roofline': {'bound': 'hbm', 'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved_gbs / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved_gbs / HBM_PEAK_GBS, 'traffic': measured_traffic(natoms, ns, args.mod),
                          'kernel': 'nm_block_kernel', 'kernel_avg_ms': k_avg_s * 1e3, 'launches': launches,
                          'algorithmic_bytes_per_launch': bytes_per_sweep * sweeps_per_launch,
                          'note': 'LDS-resident by design: the binding ceiling is fp64 VALU/latency on the CUs that hold a '
@@ -141,6 +141,16 @@ def main():
     eng.close()
     if rank == 0:
         print(json.dumps(out))
+
+
+def measured_traffic(natoms, ns, mod):
+    """HBM bytes per launch of nm_block_kernel from the committed rocprofv3 PMC passes (profiles/), for the workload
+    they were taken on; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  None for other workloads."""
+    f = os.path.join(ROOT, 'profiles', 'r01_pmc_block_kernel_cluster4.json')
+    if not (os.path.isfile(f) and natoms == 256 and ns == 64 and mod == 128):
+        return None
+    d = json.load(open(f))
+    return (2.0 * d['FETCH_SIZE']['mean'] + d['WRITE_SIZE']['mean']) * 1024.0
 
 
 def cpu_baseline(eng, natoms, args, T, P, row0):
