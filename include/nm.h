@@ -84,6 +84,9 @@ int nm_set_thermo(nm_ctx *ctx, int k0, int nk, const double *th);
 /* cycle index STEP of the main loop (remcmc:977); selects the RNG counter block. nm_run_block does not advance it. */
 int nm_set_step(nm_ctx *ctx, uint32_t step);
 
+/* the -is branch of init_sample (remcmc:421-425) for every local replica: velocity all create T, zero linear, zero
+   angular, timestep dt, run nsteps (plain NVE, no Metropolis test, counters untouched) */
+int nm_run_md(nm_ctx *ctx, int nsteps);
 /* gen_samples: MOD moves for every local replica, asynchronous on the context's stream */
 int nm_run_block(nm_ctx *ctx, int mod);
 /* rows[nslots][17] in the column order of remcmc:208 (values of the last nm_run_block; call before nm_adapt) */

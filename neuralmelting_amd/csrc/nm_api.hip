@@ -399,6 +399,18 @@ int nm_run_block(nm_ctx *c, int mod)
     return NM_OK;
 }
 
+int nm_run_md(nm_ctx *c, int nsteps)
+{
+    if (!c || nsteps < 1) return fail(c, NM_ERR_ARG, "nm_run_md: bad argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    ++c->launch_id;
+    KParams p;
+    fill_params(c, p);
+    p.mod = 1; p.md_mode = 1; p.nstps = nsteps; p.tape = nullptr;
+    HIPCHK(c, launch_kind(c, p));
+    return NM_OK;
+}
+
 int nm_get_thermo(nm_ctx *c, double *rows)
 {
     if (!c || !rows) return fail(c, NM_ERR_ARG, "nm_get_thermo: null argument");

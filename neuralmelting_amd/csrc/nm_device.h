@@ -21,6 +21,7 @@ struct KParams {
     int N, nslots, slot0;          // atoms, local replicas, global index of local slot 0
     int mod, nstps, bulk, iter_revert;
     int eval_only;                 // nm_eval: evaluate the loaded states and leave
+    int md_mode;                   // nm_run_md: velocities at T, then nstps velocity-Verlet steps, no Metropolis test
     uint32_t seed, step;
     double ppos, pvol, lat, mass;
     double kB, mvv2e, ftm2v, nktv2p;

@@ -724,9 +724,12 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
             }
             const double etotnew = R.U / et + 0.5 * p.mvv2e * R.sum_mv2() / et; // remcmc:618-622
             crit = etotnew - c_pe;
-            acc = R.metropolis(crit, S_ACC, (uint32_t)m, 0);
-            if (acc) nah += 1.0;
-            else { R.restore(true); R.wrap(); R.U = U0; R.W = W0; }
+            if (p.md_mode) acc = true; // plain NVE run (init_sample -is, remcmc:421-425): nothing to accept
+            else {
+                acc = R.metropolis(crit, S_ACC, (uint32_t)m, 0);
+                if (acc) nah += 1.0;
+                else { R.restore(true); R.wrap(); R.U = U0; R.W = W0; }
+            }
             branch = 2.0; move_done = true;
         }
         if (move_done) {
@@ -742,7 +745,7 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
         bool pending = false;
         while (m < p.mod && !pending) {
             PROF_BEGIN();
-            const double roll = R.draw_scalar(S_ROLL, (uint32_t)m, 0);
+            const double roll = p.md_mode ? 2.0 : R.draw_scalar(S_ROLL, (uint32_t)m, 0);
             if (roll <= p.ppos && p.bulk) { // bulk_position_mc, remcmc:477-484
                 ntp += 1.0;
                 R.save(false);
@@ -786,7 +789,7 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
                 phase = PH_VMC; want_e = true; pending = true;
                 PROF_END(11);
             } else { // hamiltonian_mc, remcmc:598-608
-                nth += 1.0;
+                if (!p.md_mode) nth += 1.0;
                 const uint32_t tag = R.draw_tag((uint32_t)m);
                 R.hmc_velocities(q6(t), tag);
                 c_h = uniform(q6(dt)); // timestep %f

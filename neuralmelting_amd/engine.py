@@ -117,6 +117,10 @@ class Engine:
         """gen_samples (remcmc:694-719): MOD moves for every replica, asynchronous"""
         self._chk(self.lib.nm_run_block(self.h, int(mod)))
 
+    def run_md(self, nsteps):
+        """init_sample's -is dynamics (remcmc:421-425): velocities at T, then nsteps of NVE"""
+        self._chk(self.lib.nm_run_md(self.h, int(nsteps)))
+
     def thermo(self):
         """rows[nslots][17] in the .thrm column order (remcmc:208)"""
         rows = np.empty((self.nslots, B.NM_THERMO_COLS))

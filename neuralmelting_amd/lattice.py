@@ -79,8 +79,8 @@ def init_states(sz, P, T, dx, dv, el='LJ', seed=256, row0=0, nrows=None, interpo
             xx -= np.floor(xx / b) * b
             bk = b
             if interpolate:
-                # -is (remcmc:409-419): expand the volume by exp(0.75 (j+1)/NT) about the origin.  The 1024-step NVE run
-                # with fresh velocities that follows in the reference (remcmc:421-425) is left to the first HMC moves.
+                # -is (remcmc:409-419): expand the volume by exp(0.75 (j+1)/NT) about the origin; the 1024-step NVE run with
+                # fresh velocities that follows (remcmc:421-425) is Engine.run_md
                 bk = float(np.cbrt(np.exp(np.log(b ** 3) + 0.75 * (j + 1) / nt)))
                 xx = xx * (bk / b)
             x[k] = xx.reshape(-1)

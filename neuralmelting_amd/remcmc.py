@@ -280,7 +280,11 @@ class Run:
             x, v, box, d = lattice.init_states(self.SZ, self.P, self.T, self.DX, self.DV, el=self.EL, seed=SEED,
                                                row0=self.row0, nrows=self.nrows, interpolate=self.INTSTS)
             eng.set_state(x, v, box, d)
-            eng.run_block(0)  # "run 0" of init_sample: thermo scalars of the initial states (remcmc:427)
+            if self.INTSTS:
+                eng.set_step(0xFFFFFFFE)
+                eng.run_md(1024)  # velocity create / zero / run 1024 of the -is branch (remcmc:421-425)
+            else:
+                eng.run_block(0)  # "run 0" of init_sample: thermo scalars of the initial states (remcmc:427)
         self.STEP = -1
         self.dump_samples_restart()
         for self.STEP in range(self.NSMPL):

@@ -105,5 +105,16 @@ class OracleEngine:
     def exchange(self, count=True):
         return self.loop.exchange(self.step)[0]
 
+    def run_md(self, nsteps):
+        lp = self.loop
+        for k in range(lp.ns):
+            s = self.O.Sim(lp.natoms)
+            s.set_rng(lp.seed, lp.row0 * lp.nt + k, self.step)
+            s.set_box(self.O.q6(lp.box[k])); s.set_x(lp.x[k]); s.set_v(lp.v[k]); s.setup()
+            s.velocity_create(self.O.q6(lp.tq[k]), 0); s.zero_linear(); s.zero_angular()
+            s.set_timestep(self.O.q6(lp.d[k, 2])); s.setup(); s.run(nsteps)
+            lp.x[k], lp.v[k], lp.box[k] = s.get_x(), s.get_v(), s.get_box()
+            lp.thermo[k] = [s.temp, s.pe, s.ke, s.press, s.get_box() ** 3]
+
     def synchronize(self): pass
     def close(self): pass

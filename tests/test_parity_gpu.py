@@ -167,6 +167,30 @@ def test_block_parity_large_cells(oracle, sz):
     e.close()
 
 
+def test_init_md_parity(oracle):
+    """the -is dynamics of init_sample (remcmc:421-425): velocities at T, then NVE, against the oracle's primitives"""
+    from helpers import OracleEngine
+    from neuralmelting_amd import remcmc
+    sz, nsteps = 4, 96
+    P, T = grids(1, 3)
+    loop = OracleLoop(oracle, sz, P, T)
+    e = make_engine(loop, sz, P, T)
+    e.set_step(7)
+    e.run_md(nsteps)
+    rows = e.thermo()
+    x, v, box, d = e.get_state()
+    run = remcmc.Run(['-ss', '4', '-pn', '1', '-tn', '3'])
+    oe = OracleEngine(oracle, run)
+    oe.loop = loop
+    oe.set_step(7)
+    oe.run_md(nsteps)
+    np.testing.assert_allclose(rows[:, :5], loop.thermo, rtol=RTOL)
+    np.testing.assert_allclose(x, loop.x, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(v, loop.v, rtol=0, atol=1e-7)
+    assert (rows[:, 8:] == 0).all()                      # no counters are touched
+    e.close()
+
+
 def test_sharded_rows_equal_single_context(oracle):
     """rows [0,1) and [1,2) run in two contexts reproduce the single-context result bit for bit (RNG keyed by global slot)"""
     sz, mod = 4, 8
