@@ -22,6 +22,10 @@ SYMBOLS = ('nm_create', 'nm_destroy', 'nm_last_error', 'nm_nslots', 'nm_natoms',
            'nm_get_exchange_crit')
 
 
+# include/nm_distr.h
+DISTR_SYMBOLS = ('nm_distr_histograms', 'nm_distr_last_error')
+
+
 class NMConfig(C.Structure):
     _fields_ = [('size', C.c_int32), ('element', C.c_int32), ('natoms', C.c_int32), ('np', C.c_int32),
                 ('nt', C.c_int32), ('row0', C.c_int32), ('nrows', C.c_int32), ('nstps', C.c_int32),
@@ -73,5 +77,9 @@ def load():
     for s in SYMBOLS:
         if s != 'nm_last_error':
             getattr(L, s).restype = C.c_int
+    L.nm_distr_histograms.restype = C.c_int
+    L.nm_distr_histograms.argtypes = [C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, C.c_int, c_double_p, C.c_int, c_double_p,
+                                      c_float_p, c_float_p]
+    L.nm_distr_last_error.restype = C.c_char_p
     _lib = L
     return L

@@ -10,8 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    txt = open(os.path.join(ROOT, 'include', 'nm.h')).read()
+def declared_symbols(header='nm.h'):
+    txt = open(os.path.join(ROOT, 'include', header)).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     return sorted(set(re.findall(r'\b(nm_[a-z_0-9]+)\s*\(', txt)))
 
@@ -24,6 +24,10 @@ def test_header_symbols_are_exported_and_bound():
     for s in syms:
         assert hasattr(L, s), s
     assert sorted(_lib.SYMBOLS) == syms          # the Python binding covers exactly the header
+    dsyms = declared_symbols('nm_distr.h')
+    assert dsyms == sorted(_lib.DISTR_SYMBOLS)
+    for s in dsyms:
+        assert hasattr(L, s), s
 
 
 def test_config_struct_matches_header():
