@@ -1,0 +1,92 @@
+"""GPU property tests at BASELINE's full headline size (C2: 8x8 grid of 256-atom replicas, MOD = 128) and of the cluster path."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import OracleLoop, grids
+
+pytestmark = pytest.mark.gpu
+
+
+def run_c2(cycles=3, mod=128, **env):
+    import neuralmelting_amd as nm
+    from neuralmelting_amd import lattice
+    P, T = grids(8, 8)
+    x, v, box, d = lattice.init_states(4, P, T, 0.03125, 0.03125)
+    e = nm.Engine(256, P, T)
+    e.set_state(x, v, box, d)
+    rows, perms = [], []
+    for step in range(cycles):
+        e.set_step(step)
+        e.run_block(mod)
+        rows.append(e.thermo())
+        e.adapt()
+        e.exchange()
+        perms.append(e.perm())
+    st = e.get_state()
+    q = e.cus_per_replica
+    e.close()
+    return np.array(rows), np.array(perms), st, q
+
+
+def test_c2_full_size_invariants_and_determinism():
+    rows, perms, (x, v, box, d), q = run_c2()
+    assert q == 4                                                   # 64 replicas x 4 workgroups = all 256 CUs
+    cnt = rows[:, :, 8:14]
+    np.testing.assert_array_equal(cnt[:, :, 0] + cnt[:, :, 2] + cnt[:, :, 4], 128)      # every move is a PMC, VMC or HMC trial
+    assert (cnt[:, :, 1] <= cnt[:, :, 0]).all() and (cnt[:, :, 3] <= cnt[:, :, 2]).all() and (cnt[:, :, 5] <= cnt[:, :, 4]).all()
+    ratios = rows[:, :, 14:17]
+    np.testing.assert_array_equal(ratios[:, :, 2].astype(np.float32),
+                                  (cnt[:, :, 5].astype(np.float32) / np.maximum(cnt[:, :, 4], 1).astype(np.float32)))
+    assert np.isfinite(rows).all() and (rows[:, :, 1] < 0).all() and (rows[:, :, 0] > 0).all()
+    assert (box >= 5.0).all()                                       # minimum-image regime
+    np.testing.assert_allclose(rows[:, :, 4], (rows[:, :, 4] ** (1 / 3)) ** 3)
+    # the sweep never leaves a pressure row and is a permutation inside it (remcmc:782-798)
+    for p in perms:
+        assert sorted(p) == list(range(64))
+        assert (p // 8 == np.arange(64) // 8).all()
+    # adaptive steps moved by exactly one factor per cycle (remcmc:726-745)
+    steps = rows[:, :, 5:8]
+    f = steps[1] / steps[0]
+    assert np.isin(np.round(f, 6), [0.9375, 1.0, 1.0625]).all()
+    # same seed, same machine, same binary: bit-identical replay (fixed summation orders everywhere)
+    rows2, perms2, (x2, v2, box2, d2), _ = run_c2()
+    np.testing.assert_array_equal(rows, rows2)
+    np.testing.assert_array_equal(perms, perms2)
+    np.testing.assert_array_equal(x, x2)
+    np.testing.assert_array_equal(v, v2)
+
+
+def test_velocities_have_no_net_momentum_and_target_temperature():
+    """after an accepted or rejected HMC move the stored velocities come from `velocity create`: zero COM momentum"""
+    rows, perms, (x, v, box, d), q = run_c2(cycles=1, mod=32)
+    vv = v.reshape(64, 256, 3)
+    assert np.abs(vv.sum(1)).max() < 1e-9
+    temp = rows[0, :, 0]
+    T = np.tile(np.linspace(0.25, 2.5, 8, dtype=np.float32), 8)
+    assert (np.abs(temp / T - 1) < 0.35).all()                      # kinetic temperature near the slot's temperature
+
+
+def test_cluster_matches_single_workgroup(oracle, monkeypatch):
+    """4 CUs per replica vs 1 CU per replica: same chains (only the energy summation order differs)"""
+    import neuralmelting_amd as nm
+    P, T = grids(2, 4)
+    outs = []
+    for q in ('4', '1'):
+        monkeypatch.setenv('NM_CUS_PER_REPLICA', q)
+        loop = OracleLoop(oracle, 4, P, T)
+        e = nm.Engine(256, P, T)
+        assert e.cus_per_replica == int(q)
+        e.set_state(loop.x, loop.v, loop.box, loop.d)
+        e.set_trace(True)
+        for step in range(2):
+            e.set_step(step); e.run_block(48); e.adapt(); e.exchange()
+        outs.append((e.thermo(), e.trace(48), e.get_state(), e.perm()))
+        e.close()
+    (r4, t4, s4, p4), (r1, t1, s1, p1) = outs
+    np.testing.assert_array_equal(t4[:, :, :2], t1[:, :, :2])       # branches and decisions
+    np.testing.assert_allclose(t4[:, :, 2:], t1[:, :, 2:], rtol=1e-9, atol=1e-9)
+    np.testing.assert_array_equal(p4, p1)
+    np.testing.assert_allclose(s4[0], s1[0], rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(s4[3], s1[3])
