@@ -32,6 +32,7 @@ def main():
     ap.add_argument('--rows', type=int, default=8, help='pressure rows per GPU')
     ap.add_argument('--tn', type=int, default=8, help='temperatures (-tn)')
     ap.add_argument('--mod', type=int, default=128, help='moves per block (-sm)')
+    ap.add_argument('--el', type=str, default='LJ', help="element (-e): LJ, or Al = BASELINE config 4 (Sutton-Chen EAM, metal units)")
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--cpu-cycles', type=int, default=2)
     args = ap.parse_args()
@@ -56,11 +57,11 @@ def main():
 
     npn = args.rows * world
     P = np.linspace(1.0, 8.0, npn, dtype=np.float32)
-    T = np.linspace(0.25, 2.5, args.tn, dtype=np.float32)
+    T = np.linspace(0.25, 2.5, args.tn, dtype=np.float32) if args.el == 'LJ' else np.linspace(256.0, 2560.0, args.tn, dtype=np.float32)
     natoms = 4 * args.sz ** 3
     row0 = rank * args.rows
-    x, v, box, d = lattice.init_states(args.sz, P, T, 0.03125, 0.03125, row0=row0, nrows=args.rows)
-    eng = nm.Engine(natoms, P, T, device=local, row0=row0, nrows=args.rows, ppos=0.125, pvol=0.125, nstps=8,
+    x, v, box, d = lattice.init_states(args.sz, P, T, 0.03125, 0.03125, el=args.el, row0=row0, nrows=args.rows)
+    eng = nm.Engine(natoms, P, T, element=args.el, device=local, row0=row0, nrows=args.rows, ppos=0.125, pvol=0.125, nstps=8,
                     bulk=True, seed=256)
     eng.set_state(x, v, box, d)
     ns = eng.nslots
@@ -115,12 +116,12 @@ def main():
         flops = evals * mean_pairs * FLOP_PER_PAIR
         tf = flops / (kms * 1e-3) / 1e12
         out = {
-            'metric': 'MC sweeps/sec (whole node), LJ 4^3 cells, 8x8 PxT grid',
+            'metric': 'MC sweeps/sec (whole node), %s 4^3 cells, 8x8 PxT grid' % args.el,
             'value': value, 'unit': 'sweeps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'LJ %d^3 cells (%d atoms), %dx%d PxT grid per GPU, MOD=%d, bulk PMC 0.125 / VMC 0.125 / '
-                                   'HMC 0.75 x %d steps, outputs off' % (args.sz, natoms, args.rows, args.tn, args.mod, 8),
+            'config': {'workload': '%s %d^3 cells (%d atoms), %dx%d PxT grid per GPU, MOD=%d, bulk PMC 0.125 / VMC 0.125 / '
+                                   'HMC 0.75 x %d steps, outputs off' % (args.el, args.sz, natoms, args.rows, args.tn, args.mod, 8),
                        'replicas_per_gpu': ns, 'sweeps_per_step': world * ns * args.mod, 'parallelism': 'rows/gpu'},
             'roofline': {'bound': 'hbm', 'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved_gbs / HBM_PEAK_GBS, 'traffic': measured_traffic(natoms, ns, args.mod),
@@ -156,6 +157,7 @@ def measured_traffic(natoms, ns, mod):
 def cpu_baseline(eng, natoms, args, T, P, row0):
     """the oracle (C restatement, OpenMP over replicas) timed on the host cores on the engine's current states"""
     from oracle import oracle as O
+    from neuralmelting_amd import lattice
     O.build()
     x, v, box, d = eng.get_state()
     et, pf = eng.constants()
@@ -168,8 +170,10 @@ def cpu_baseline(eng, natoms, args, T, P, row0):
     cores = min(cores, ns)  # one replica per thread: more threads than replicas would idle
     t0 = time.perf_counter()
     for c in range(args.cpu_cycles):
-        out = O.run_blocks(x, v, box, d, et, et, pf, natoms=natoms, mod=args.mod, nstps=8, bulk=True, ppos=0.125,
-                           pvol=0.125, lat=1.122, seed=256, slot0=row0 * len(T), step=1000 + c, nthreads=cores)
+        kw = dict(units=1, mass=lattice.MASS['Al'], pot=1) if args.el == 'Al' else {}
+        tq = np.tile(T.astype(np.float64), args.rows)
+        out = O.run_blocks(x, v, box, d, tq, et, pf, natoms=natoms, mod=args.mod, nstps=8, bulk=True, ppos=0.125,
+                           pvol=0.125, lat=lattice.LAT[args.el][1], seed=256, slot0=row0 * len(T), step=1000 + c, nthreads=cores, **kw)
         x, v, box = out['x'], out['v'], out['box']
     dt = time.perf_counter() - t0
     return {'value': ns * args.mod * args.cpu_cycles / dt, 'unit': 'sweeps/s', 'cores': cores, 'kind': 'port',

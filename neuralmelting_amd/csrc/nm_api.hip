@@ -25,6 +25,10 @@ namespace {
 typedef Cfg<NM_SMALL_BLOCK, 2 * NM_SMALL_TPA, 256, 160, unsigned char, true, true> CfgSmallQ2;
 typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 160, unsigned char, true, true> CfgSmallQ4;
 typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 160, unsigned char, true, true> CfgSmall;     // N <= 256: everything incl. the byte list in LDS
+// element Al: Sutton-Chen EAM, 4^3 cells only (BASELINE config 4); 200 neighbour slots (134 within rc+skin in the crystal)
+typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 200, unsigned char, true, true, 1> CfgSmallSC;
+typedef Cfg<NM_SMALL_BLOCK, 2 * NM_SMALL_TPA, 256, 200, unsigned char, true, true, 1> CfgSmallSCQ2;
+typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 200, unsigned char, true, true, 1> CfgSmallSCQ4;
 typedef Cfg<512, 1, 864, 160, unsigned short, false, true> CfgMid;     // N <= 864: list in HBM/L2, saved copies in LDS
 typedef Cfg<512, 1, 864, 160, unsigned short, false, true> CfgMidQ2;   // cluster variants: own atoms 432 / 216 / 108
 typedef Cfg<512, 2, 864, 160, unsigned short, false, true> CfgMidQ4;
@@ -44,7 +48,8 @@ struct nm_ctx {
     double *d_xbuf;
     uint32_t launch_id;
     size_t lds_bytes, aux_doubles;
-    double lat, mass, kB, mvv2e, ftm2v, nktv2p, skin;
+    double lat, mass, kB, mvv2e, ftm2v, nktv2p, skin, rc;
+    int pot; // 0 lj/cut, 1 Sutton-Chen EAM
     uint32_t step;
     hipStream_t stream;
     // device
@@ -92,7 +97,8 @@ void fill_params(const nm_ctx *c, KParams &p)
     p.seed = c->cfg.seed; p.step = c->step;
     p.ppos = c->cfg.ppos; p.pvol = c->cfg.pvol; p.lat = c->lat; p.mass = c->mass;
     p.kB = c->kB; p.mvv2e = c->mvv2e; p.ftm2v = c->ftm2v; p.nktv2p = c->nktv2p;
-    p.rc = 2.5; p.skin = c->skin;
+    p.rc = c->rc; p.skin = c->skin;
+    p.sc_eps = 0.033147; p.sc_a2 = 4.05 * 4.05; p.sc_c = 16.399; // Sutton & Chen, Phil. Mag. Lett. 61 (1990) 139: Al
     p.x = c->d_x; p.v = c->d_v; p.box = c->d_box; p.steps = c->d_steps; p.therm = c->d_therm;
     p.count = c->d_count; p.ratio = c->d_ratio; p.slot2buf = c->d_slot2buf;
     p.et = c->d_et; p.pf = c->d_pf; p.tq = c->d_tq;
@@ -115,7 +121,9 @@ hipError_t launch_block(const nm_ctx *c, const KParams &p)
 hipError_t launch_kind(const nm_ctx *c, const KParams &p)
 {
     switch (c->kind) {
-    case 0: return c->cus == 4 ? launch_block<CfgSmallQ4>(c, p) : c->cus == 2 ? launch_block<CfgSmallQ2>(c, p) : launch_block<CfgSmall>(c, p);
+    case 0:
+        if (c->pot == 1) return c->cus == 4 ? launch_block<CfgSmallSCQ4>(c, p) : c->cus == 2 ? launch_block<CfgSmallSCQ2>(c, p) : launch_block<CfgSmallSC>(c, p);
+        return c->cus == 4 ? launch_block<CfgSmallQ4>(c, p) : c->cus == 2 ? launch_block<CfgSmallQ2>(c, p) : launch_block<CfgSmall>(c, p);
     case 1: return c->cus == 8 ? launch_block<CfgMidQ8>(c, p) : c->cus == 4 ? launch_block<CfgMidQ4>(c, p) : launch_block<CfgMid>(c, p);
     default: return launch_block<CfgLarge>(c, p);
     }
@@ -171,8 +179,10 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     if (!cfg->P || !cfg->T) return fail(nullptr, NM_ERR_ARG, "nm_create: P and T grids are required");
     if (cfg->nstps < 1 || cfg->ppos < 0 || cfg->pvol < 0 || cfg->ppos + cfg->pvol > 1.0)
         return fail(nullptr, NM_ERR_ARG, "nm_create: bad move parameters");
-    if (cfg->element != NM_EL_LJ)
-        return fail(nullptr, NM_ERR_UNSUPPORTED, "nm_create: only element LJ has a device force kernel in this build");
+    if (cfg->element != NM_EL_LJ && cfg->element != NM_EL_AL)
+        return fail(nullptr, NM_ERR_UNSUPPORTED, "nm_create: elements LJ and Al have device force kernels in this build");
+    if (cfg->element == NM_EL_AL && cfg->natoms > 256)
+        return fail(nullptr, NM_ERR_UNSUPPORTED, "nm_create: element Al (EAM) is built for up to 256 atoms (4^3 cells)");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -191,20 +201,32 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     c->skin = 0.3; // Verlet-list skin: not observable in results, only in the rebuild rate
     if (const char *e = std::getenv("NM_SKIN")) { const double v = std::atof(e); if (v > 0.0 && v < 1.0) c->skin = v; }
     c->lat = 1.122; c->mass = 1.0; c->kB = 1.0; c->mvv2e = 1.0; c->ftm2v = 1.0; c->nktv2p = 1.0;
+    c->rc = 2.5; c->pot = 0;
+    if (cfg->element == NM_EL_AL) { // units metal (LAMMPS update.cpp constants), remcmc:880,886
+        c->lat = 4.046; c->mass = 29.982; c->kB = 8.617343e-5; c->mvv2e = 1.0364269e-4; c->ftm2v = 1.0 / 1.0364269e-4;
+        c->nktv2p = 1.6021765e6; c->rc = 7.5; c->skin = 0.8; c->pot = 1;
+        if (const char *e = std::getenv("NM_SKIN_AL")) { const double v = std::atof(e); if (v > 0.0 && v < 3.0) c->skin = v; }
+    }
 
     // init_constant (remcmc:114-132) in float64 on the float32-rounded grid values (NumPy-1.x promotion)
     c->h_et.resize(c->nslots); c->h_pf.resize(c->nslots); c->h_tq.resize(c->nslots);
     for (int k = 0; k < c->nslots; ++k) {
         const int i = cfg->row0 + k / cfg->nt, j = k % cfg->nt;
         const double Pi = (double)cfg->P[i], Tj = (double)cfg->T[j];
-        const double kb = 1.0;
-        c->h_et[k] = kb * Tj;
-        c->h_pf[k] = Pi / (kb * Tj);
+        if (cfg->element == NM_EL_AL) { // remcmc:124-127
+            const double kb = 8.61733e-5;
+            c->h_et[k] = kb * Tj;
+            c->h_pf[k] = 1e-30 * (1e5 * Pi) / (1.60218e-19 * kb * Tj);
+        } else {                        // remcmc:128-131
+            const double kb = 1.0;
+            c->h_et[k] = kb * Tj;
+            c->h_pf[k] = Pi / (kb * Tj);
+        }
         c->h_tq[k] = Tj;
     }
 
     size_t nbr_elems;
-    if (c->N <= CfgSmall::NMAX) { c->kind = 0; c->lds_bytes = CfgSmall::LDS_BYTES; c->aux_doubles = CfgSmall::AUX_DOUBLES; nbr_elems = CfgSmall::NBR_G_ELEMS; }
+    if (c->N <= CfgSmall::NMAX) { c->kind = 0; c->lds_bytes = c->pot == 1 ? CfgSmallSC::LDS_BYTES : CfgSmall::LDS_BYTES; c->aux_doubles = CfgSmall::AUX_DOUBLES; nbr_elems = CfgSmall::NBR_G_ELEMS; }
     else if (c->N <= CfgMid::NMAX) { c->kind = 1; c->lds_bytes = CfgMid::LDS_BYTES; c->aux_doubles = CfgMid::AUX_DOUBLES; nbr_elems = CfgMid::NBR_G_ELEMS; }
     else { c->kind = 2; c->lds_bytes = CfgLarge::LDS_BYTES; c->aux_doubles = CfgLarge::AUX_DOUBLES; nbr_elems = CfgLarge::NBR_G_ELEMS; }
 
@@ -264,9 +286,12 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     CHK(hipMemcpy(c->d_tq, c->h_tq.data(), ns * sizeof(double), hipMemcpyHostToDevice));
     // dynamic LDS above 64 KiB has to be requested per kernel
     if (c->kind == 0) {
-        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
-        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallQ2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
-        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallQ4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmall::LDS_BYTES));
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallQ2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmall::LDS_BYTES));
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallQ4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmall::LDS_BYTES));
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallSC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmallSC::LDS_BYTES));
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallSCQ2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmallSC::LDS_BYTES));
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallSCQ4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmallSC::LDS_BYTES));
     }
     else if (c->kind == 1) {
         CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgMid>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));

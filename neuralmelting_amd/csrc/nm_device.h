@@ -26,6 +26,7 @@ struct KParams {
     double ppos, pvol, lat, mass;
     double kB, mvv2e, ftm2v, nktv2p;
     double rc, skin;
+    double sc_eps, sc_a2, sc_c;    // Sutton-Chen EAM (element Al): E = eps [ 1/2 sum (a/r)^7 - c sum sqrt(rho) ], rho = sum (a/r)^6
     // per buffer
     double *x, *v, *box, *steps, *therm;
     // per slot

@@ -32,8 +32,9 @@ constexpr int NVMAX = 12; // widest block reduction (momentum 3 + angular moment
 // NMAX (array stride) and MAXNB (neighbour slots per atom) are compile-time so that every LDS array sits at a
 // constant offset: no address registers are needed for them (with run-time strides the eighteen array bases were
 // spilled to scratch and reloaded inside the pair loop).
-template <int BLOCK_, int TPA_, int NMAX_, int MAXNB_, typename IdxT_, bool LIST_LDS_, bool SAVE_LDS_>
+template <int BLOCK_, int TPA_, int NMAX_, int MAXNB_, typename IdxT_, bool LIST_LDS_, bool SAVE_LDS_, int POT_ = 0>
 struct Cfg {
+    static constexpr int POT = POT_; // 0 = lj/cut 2.5, 1 = Sutton-Chen EAM (two-pass: densities, then forces)
     static constexpr int BLOCK = BLOCK_, TPA = TPA_, NW = BLOCK_ / 64, G = BLOCK_ / TPA_, NMAX = NMAX_, MAXNB = MAXNB_;
     static constexpr bool LIST_LDS = LIST_LDS_, SAVE_LDS = SAVE_LDS_;
     using IdxT = IdxT_;
@@ -47,12 +48,14 @@ struct Cfg {
     static constexpr size_t OFF_IMG = OFF_CNT + pad8((size_t)NMAX * sizeof(unsigned short));
     static constexpr size_t OFF_WN = OFF_IMG + pad8((size_t)3 * NMAX * sizeof(short));
     static constexpr size_t OFF_NBR = SAVE_LDS ? OFF_WN + pad8((size_t)3 * NMAX) : OFF_IMG;
-    static constexpr size_t LDS_BYTES = LIST_LDS ? OFF_NBR + pad8((size_t)MAXNB * NMAX * sizeof(IdxT)) : OFF_NBR;
+    static constexpr size_t OFF_RHO = LIST_LDS ? OFF_NBR + pad8((size_t)MAXNB * NMAX * sizeof(IdxT)) : OFF_NBR; // EAM densities
+    static constexpr size_t LDS_BYTES = OFF_RHO + (POT ? (size_t)NMAX * sizeof(double) : 0);
     // per-slot global spill when the saved copies do not fit in LDS: sav, savv, x0 (9 NMAX doubles) + images + wrap counts
     static constexpr size_t AUX_DOUBLES = SAVE_LDS ? 0 : (size_t)9 * NMAX + ((size_t)3 * NMAX * 3 + 7) / 8;
     static constexpr size_t NBR_G_ELEMS = LIST_LDS ? 0 : (size_t)MAXNB * NMAX; // per-slot global list
     static constexpr int QMAX = 8;                                               // most workgroups per replica
-    static constexpr size_t XBUF_GRANULES = (size_t)3 * NMAX + 4 * QMAX;         // forces by component + per-workgroup partials
+    static constexpr size_t XBUF_GRANULES = (size_t)4 * NMAX + 4 * QMAX;         // forces by component, EAM densities, per-workgroup partials
+    static constexpr size_t XG_PART = (size_t)3 * NMAX, XG_RHO = (size_t)3 * NMAX + 4 * QMAX; // granule indices
     static constexpr size_t XBUF_DOUBLES = 2 * XBUF_GRANULES;                    // one exchange buffer (there are two per slot)
 };
 
@@ -74,6 +77,7 @@ struct Replica {
     unsigned short *cnt;
     IdxT *nbr;
     double *red;
+    double *rho; // EAM: densities, then 1/sqrt(density)
     int parity = 0;
     // block-uniform scalars
     double L = 0.0, L0 = 0.0, U = 0.0, W = 0.0;
@@ -93,6 +97,7 @@ struct Replica {
         vx = (double *)(smem + C::OFF_VEL); vy = vx + NMAX; vz = vy + NMAX;
         fx = (double *)(smem + C::OFF_FRC); fy = fx + NMAX; fz = fy + NMAX;
         red = (double *)(smem + C::OFF_RED);
+        rho = (double *)(smem + C::OFF_RHO);
         cnt = (unsigned short *)(smem + C::OFF_CNT);
         if constexpr (C::SAVE_LDS) {
             sx = (double *)(smem + C::OFF_SAV); svx = (double *)(smem + C::OFF_SAVV); x0 = (double *)(smem + C::OFF_X0);
@@ -317,6 +322,14 @@ struct Replica {
         }
     }
 
+    // ------------------------------------------------------------------ Sutton-Chen EAM (element Al; the build's own choice
+    // for BASELINE config 4: the reference's MEAM parameter files are not part of its tree)
+    // E = eps [ 1/2 sum_ij (a/r)^7 - c sum_i sqrt(rho_i) ],  rho_i = sum_j (a/r)^6,  r < rc.
+    // Two passes over the same full list: densities of the own atoms, (cluster: exchange them,) then forces with
+    // fp = eps [ 7 (a/r)^7 - 6 (c/2)(1/sqrt(rho_i) + 1/sqrt(rho_j)) (a/r)^6 ] / r^2.
+    template <bool WANT_E>
+    __device__ __forceinline__ void pair_loop_sc(double invL, double &eacc, double &wacc, double &nacc);
+
     // ------------------------------------------------------------------ cluster hand-off (Q workgroups per replica)
     // Data-tagged granules (MI355X guide, hand-off price list "handoff-1to1"): every exchanged double travels as ONE
     // 16-byte write-through (sc1) store {bits, bits ^ magic}, magic = f(launch, evaluation).  A reader polls the granule
@@ -371,7 +384,7 @@ struct Replica {
         const unsigned long long mg = magic();
         if (tid < 4) { // this workgroup's partial sums and status bits
             const double v = tid == 0 ? s[0] : tid == 1 ? s[1] : tid == 2 ? s[2] : (double)status;
-            put_granule(xg + 2 * (size_t)(3 * NMAX + 4 * q + tid), v, mg);
+            put_granule(xg + 2 * (size_t)(C::XG_PART + 4 * q + tid), v, mg);
         }
         int timeout = 0;
         // forces of the atoms the other workgroups own: one thread per atom, three granules in flight
@@ -386,9 +399,9 @@ struct Replica {
         double t0s = 0.0, t1s = 0.0, t2s = 0.0;
         int st = 0;
         for (int r = 0; r < Q; ++r) {
-            double *const gs[3] = { xg + 2 * (size_t)(3 * NMAX + 4 * r), xg + 2 * (size_t)(3 * NMAX + 4 * r + 1),
-                                    xg + 2 * (size_t)(3 * NMAX + 4 * r + 2) };
-            double *const gt[1] = { xg + 2 * (size_t)(3 * NMAX + 4 * r + 3) };
+            double *const gs[3] = { xg + 2 * (C::XG_PART + 4 * r), xg + 2 * (C::XG_PART + 4 * r + 1),
+                                    xg + 2 * (C::XG_PART + 4 * r + 2) };
+            double *const gt[1] = { xg + 2 * (C::XG_PART + 4 * r + 3) };
             double v3[3] = { 0.0, 0.0, 0.0 }, v1[1] = { 0.0 };
             if (want_e && get_granules<3>(gs, mg, v3, timeout)) { t0s += v3[0]; t1s += v3[1]; t2s += v3[2]; }
             if (get_granules<1>(gt, mg, v1, timeout)) st |= (int)v1[0];
@@ -435,6 +448,7 @@ struct Replica {
         double eacc = 0.0, wacc = 0.0, nacc = 0.0;
         PROF_BEGIN();
         if (p.dbg & 16) { }
+        else if constexpr (C::POT == 1) { if (want_e) pair_loop_sc<true>(invL, eacc, wacc, nacc); else pair_loop_sc<false>(invL, eacc, wacc, nacc); }
         else if (want_e) pair_loop<true>(invL, eacc, wacc, nacc);
         else pair_loop<false>(invL, eacc, wacc, nacc);
         PROF_END(3);
@@ -612,6 +626,96 @@ struct Replica {
         return nacc;
     }
 };
+
+template <class C>
+template <bool WANT_E>
+__device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &eacc, double &wacc, double &nacc)
+{
+    const int g = tid / TPA, sub = tid - g * TPA;
+    const double rc2 = p.rc * p.rc, a2 = p.sc_a2, eps = p.sc_eps, cc = p.sc_c;
+    double *xg = xb ? xb + (size_t)(gen & 1) * C::XBUF_DOUBLES : nullptr;
+    const unsigned long long mg = magic();
+    // pass 1: densities of this workgroup's atoms
+    for (int i0 = a0; i0 < a1; i0 += G) {
+        const int i = i0 + g;
+        double r = 0.0;
+        if (i < a1) {
+            const double xi = px[i], yi = py[i], zi = pz[i];
+            const int c = cnt[i];
+            for (int s = sub; s < c; s += TPA) {
+                const int j = nbr[(size_t)s * NMAX + i];
+                double dx = xi - px[j], dy = yi - py[j], dz = zi - pz[j];
+                dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                const double q2 = a2 * recip(r2);
+                r += (r2 < rc2) ? q2 * q2 * q2 : 0.0;
+            }
+        }
+#pragma unroll
+        for (int off = TPA / 2; off >= 1; off >>= 1) r += __shfl_xor(r, off, 64);
+        if (i < a1 && sub == 0) {
+            rho[i] = r;
+            if (Q > 1) put_granule(xg + 2 * (C::XG_RHO + i), r, mg);
+        }
+    }
+    int timeout = 0;
+    if (Q > 1) { // densities of the atoms the other workgroups own
+        const int nother = N - (a1 - a0);
+        for (int o = tid; o < nother; o += BLOCK) {
+            const int i = o < a0 ? o : o + (a1 - a0);
+            double *const g1[1] = { xg + 2 * (C::XG_RHO + i) };
+            double v1[1];
+            if (get_granules<1>(g1, mg, v1, timeout)) rho[i] = v1[0];
+        }
+    }
+    if (block_any<NW, NVMAX>(timeout != 0, red, parity)) { status |= ST_SYNC_TIMEOUT; return; }
+    double sq_own = 0.0; // sum over own atoms of sqrt(rho_i), by the atom's elementwise owner
+    for (int i = tid; i < N; i += BLOCK) {
+        const double sr = sqrt(rho[i]);
+        if (i >= a0 && i < a1) sq_own += sr;
+        rho[i] = 1.0 / sr;
+    }
+    __syncthreads();
+    // pass 2: forces (and energy, virial) of this workgroup's atoms
+    for (int i0 = a0; i0 < a1; i0 += G) {
+        const int i = i0 + g;
+        double ax = 0.0, ay = 0.0, az = 0.0, e = 0.0, w = 0.0, np = 0.0;
+        if (i < a1) {
+            const double xi = px[i], yi = py[i], zi = pz[i], isi = rho[i];
+            const int c = cnt[i];
+            for (int s = sub; s < c; s += TPA) {
+                const int j = nbr[(size_t)s * NMAX + i];
+                double dx = xi - px[j], dy = yi - py[j], dz = zi - pz[j];
+                dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                const bool in = r2 < rc2;
+                const double r2i = recip(r2);
+                const double q2 = a2 * r2i;
+                const double rm = q2 * q2 * q2;        // (a/r)^6
+                const double rn = rm * sqrt(q2);       // (a/r)^7
+                const double dF = 0.5 * cc * (isi + rho[j]);
+                const double fp = in ? eps * (7.0 * rn - 6.0 * dF * rm) * r2i : 0.0;
+                ax += dx * fp; ay += dy * fp; az += dz * fp;
+                if (WANT_E) { e += in ? eps * rn : 0.0; w += r2 * fp; np += in ? 1.0 : 0.0; }
+            }
+        }
+#pragma unroll
+        for (int off = TPA / 2; off >= 1; off >>= 1) {
+            ax += __shfl_xor(ax, off, 64); ay += __shfl_xor(ay, off, 64); az += __shfl_xor(az, off, 64);
+            if (WANT_E) { e += __shfl_xor(e, off, 64); w += __shfl_xor(w, off, 64); np += __shfl_xor(np, off, 64); }
+        }
+        if (i < a1 && sub == 0) {
+            fx[i] = ax; fy[i] = ay; fz[i] = az; eacc += e; wacc += w; nacc += np;
+            if (Q > 1) {
+                put_granule(xg + 2 * (size_t)i, ax, mg);
+                put_granule(xg + 2 * (size_t)(NMAX + i), ay, mg);
+                put_granule(xg + 2 * (size_t)(2 * NMAX + i), az, mg);
+            }
+        }
+    }
+    // the caller halves the summed energy (pair terms are counted twice in a full list): fold the embedding term in as -2 eps c sqrt(rho)
+    eacc -= 2.0 * eps * cc * sq_own;
+}
 
 // Phases of the per-replica state machine.  The block kernel is written so that eval() — by far the largest
 // piece of code and the only one whose cost matters — has exactly ONE call site; every move is split into the

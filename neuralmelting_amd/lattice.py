@@ -40,12 +40,45 @@ def lj_static(frac, box):
     return float((r6i * (4.0 * r6i - 4.0)).sum()), float((r6i * (48.0 * r6i - 24.0)).sum())
 
 
+# Sutton-Chen Al (Phil. Mag. Lett. 61 (1990) 139), the engine's EAM for element Al; rc as in the kernels
+SC_EPS, SC_A, SC_C, SC_RC = 0.033147, 4.05, 16.399, 7.5
+NKTV2P_METAL = 1.6021765e6  # eV/A^3 -> bar (LAMMPS metal units)
+
+
+def sc_static(frac, box):
+    """U [eV] and W = sum r.f [eV] of the Sutton-Chen potential for fractional coordinates in a cubic box (numpy, O(N^2))"""
+    d = frac[:, None, :] - frac[None, :, :]
+    d -= np.rint(d)
+    r2 = (d * d).sum(-1) * box * box
+    np.fill_diagonal(r2, np.inf)
+    q2 = np.where(r2 < SC_RC * SC_RC, SC_A * SC_A / r2, 0.0)
+    rm = q2 ** 3
+    rn = rm * np.sqrt(q2)
+    rho = rm.sum(1)
+    isr = 1.0 / np.sqrt(rho)
+    u = SC_EPS * (0.5 * rn.sum() - SC_C * np.sqrt(rho).sum())
+    dF = 0.5 * SC_C * (isr[:, None] + isr[None, :])
+    w = 0.5 * (SC_EPS * (7.0 * rn - 6.0 * dF * rm)).sum()     # r2*fp summed over pairs once
+    return float(u), float(w)
+
+
 def relax_box(sz, press, el='LJ'):
-    """box edge at which the static virial pressure W/(3V) of the perfect lattice equals `press`"""
-    if UNITS[el] != 'lj':
-        raise NotImplementedError('static relaxation is implemented for the LJ potential')
+    """box edge at which the static virial pressure W/(3V) of the perfect lattice equals `press`
+    (lj units: reduced pressure; metal units: bar)"""
     frac = fcc_fractional(sz)
     a0 = sz * lattice_constant(el)
+    if UNITS[el] == 'metal':
+        if el != 'Al':
+            raise NotImplementedError('only Al has a potential among the metal-unit elements')
+
+        def f(box):
+            return sc_static(frac, box)[1] / (3.0 * box ** 3) * NKTV2P_METAL - press
+        lo, hi = 0.97 * a0, 1.03 * a0
+        while f(lo) < 0:
+            lo *= 0.99
+        while f(hi) > 0:
+            hi *= 1.01
+        return brentq(f, lo, hi, xtol=1e-12, rtol=1e-14)
 
     def f(box):
         return lj_static(frac, box)[1] / (3.0 * box ** 3) - press

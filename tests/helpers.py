@@ -20,11 +20,21 @@ def constants_lj(P, T, row0=0, nrows=None):
     return et, pf, tq
 
 
+def constants_metal(P, T, row0=0, nrows=None):
+    """init_constant for metal units (remcmc:124-127)"""
+    nrows = len(P) - row0 if nrows is None else nrows
+    kb = 8.61733e-5
+    et = np.array([kb * float(T[j]) for r in range(nrows) for j in range(len(T))])
+    pf = np.array([1e-30 * (1e5 * float(P[row0 + r])) / (1.60218e-19 * kb * float(T[j])) for r in range(nrows) for j in range(len(T))])
+    tq = np.array([float(T[j]) for r in range(nrows) for j in range(len(T))])
+    return et, pf, tq
+
+
 class OracleLoop:
     """gen_samples / gen_mc_params / replica_exchange on the oracle, holding STATE like the reference does"""
 
     def __init__(self, O, sz, P, T, *, dx=0.03125, dv=0.03125, ppos=0.125, pvol=0.125, nstps=8, bulk=True, seed=256,
-                 row0=0, nrows=None, iter_revert=False, nthreads=0):
+                 row0=0, nrows=None, iter_revert=False, nthreads=0, el='LJ'):
         self.O = O
         self.P, self.T = P, T
         self.nt = len(T)
@@ -32,11 +42,14 @@ class OracleLoop:
         self.nrows = len(P) - row0 if nrows is None else nrows
         self.ns = self.nrows * self.nt
         self.natoms = 4 * sz ** 3
-        self.kw = dict(natoms=self.natoms, nstps=nstps, bulk=bulk, ppos=ppos, pvol=pvol, lat=LAT_LJ, seed=seed,
+        self.el = el
+        self.kw = dict(natoms=self.natoms, nstps=nstps, bulk=bulk, ppos=ppos, pvol=pvol, lat=lattice.LAT[el][1], seed=seed,
                        iter_revert=iter_revert, nthreads=nthreads)
+        if el == 'Al':
+            self.kw.update(units=1, mass=lattice.MASS['Al'], pot=1)
         self.seed = seed
-        self.x, self.v, self.box, self.d = lattice.init_states(sz, P, T, dx, dv, seed=seed, row0=row0, nrows=self.nrows)
-        self.et, self.pf, self.tq = constants_lj(P, T, row0, self.nrows)
+        self.x, self.v, self.box, self.d = lattice.init_states(sz, P, T, dx, dv, el=el, seed=seed, row0=row0, nrows=self.nrows)
+        self.et, self.pf, self.tq = (constants_lj if el == 'LJ' else constants_metal)(P, T, row0, self.nrows)
         self.thermo = np.zeros((self.ns, 5))
         self.thermo[:, 4] = self.box ** 3
         self.counters = np.zeros((self.ns, 6))

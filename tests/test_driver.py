@@ -103,6 +103,15 @@ def test_driver_end_to_end_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_driver_al_eam_gpu(tmp_path):
+    """-e Al (BASELINE config 4 family): metal units, EAM kernel, same file layout"""
+    argv = '-bm -n al1 -e Al -ss 4 -pn 2 -tn 2 -pr 1 8 -tr 300 900 -sn 2 -sm 8'.split()
+    run = run_driver(tmp_path, argv)
+    cols = check_outputs(tmp_path, run, nrec=2)
+    assert (cols[0] > 50).all() and (cols[1] < -700).all()      # kelvin; ~ -3.3 eV/atom x 256
+
+
+@pytest.mark.gpu
 def test_driver_matches_oracle_driver(tmp_path, oracle):
     """same flags through the HIP engine and through the oracle stand-in give the same .thrm rows (5 significant digits)"""
     argv = '-bm -e LJ -ss 4 -pn 2 -tn 2 -sn 3 -sm 6'.split()

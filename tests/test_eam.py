@@ -1,0 +1,93 @@
+"""element Al: Sutton-Chen EAM (the build's own choice for BASELINE config 4; no reference parameters exist, so this is
+oracle <-> HIP parity plus self-consistency, not parity with the reference: "parity unpinned" for the potential itself)"""
+import numpy as np
+import pytest
+
+from helpers import OracleLoop, grids
+from neuralmelting_amd import lattice
+
+
+def al_sample(oracle, amp=0.15, seed=2):
+    box = 4 * lattice.lattice_constant('Al')
+    x = lattice.fcc_fractional(4) * box
+    rng = np.random.default_rng(seed)
+    x = x + amp * (rng.random(x.shape) - 0.5)
+    s = oracle.Sim(256, units=1, mass=lattice.MASS['Al'], pot=1)
+    s.set_box(box); s.set_x(x.ravel()); s.set_v(np.zeros(768)); s.setup()
+    return s, x, box
+
+
+def test_oracle_sc_forces_are_energy_gradient(oracle):
+    s, x, box = al_sample(oracle)
+    f = s.get_f().reshape(-1, 3)
+    h = 1e-5
+    for (i, c) in ((0, 0), (17, 1), (255, 2)):
+        xp = x.copy(); xp[i, c] += h
+        xm = x.copy(); xm[i, c] -= h
+        s.set_x(xp.ravel()); s.setup(); ep = s.pe
+        s.set_x(xm.ravel()); s.setup(); em = s.pe
+        assert abs(-(ep - em) / (2 * h) - f[i, c]) < 5e-6 * max(1.0, abs(f[i, c]))
+
+
+def test_oracle_sc_matches_numpy_static(oracle):
+    box = 4 * lattice.lattice_constant('Al')
+    frac = lattice.fcc_fractional(4)
+    u, w = lattice.sc_static(frac, box)
+    s = oracle.Sim(256, units=1, mass=lattice.MASS['Al'], pot=1)
+    s.set_box(box); s.set_x((frac * box).ravel()); s.set_v(np.zeros(768)); s.setup()
+    assert abs(s.pe - u) < 1e-9 * abs(u) and abs(s.virial - w) < 1e-8 * max(1.0, abs(w))
+    assert -3.6 < u / 256 < -3.0            # Sutton-Chen Al cohesive energy, slightly reduced by the 7.5 A cutoff
+    assert np.abs(s.get_f()).max() < 1e-9
+    b0 = lattice.relax_box(4, 0.0, 'Al')
+    assert abs(b0 / 4 - 4.05) < 0.06        # zero-pressure lattice constant close to Sutton-Chen's a
+
+
+@pytest.mark.gpu
+def test_eam_eval_parity(oracle):
+    import neuralmelting_amd as nm
+    P, T = grids(2, 2, pr=(1.0, 8.0), tr=(300.0, 900.0))
+    loop = OracleLoop(oracle, 4, P, T, el='Al')
+    e = nm.Engine(256, P, T, element='Al')
+    e.set_state(loop.x, loop.v, loop.box, loop.d)
+    et, pf = e.constants()
+    np.testing.assert_array_equal(et, loop.et)
+    np.testing.assert_array_equal(pf, loop.pf)
+    U, W, f = e.eval()
+    for k in range(loop.ns):
+        s = oracle.Sim(256, units=1, mass=lattice.MASS['Al'], pot=1)
+        s.set_box(loop.box[k]); s.set_x(loop.x[k]); s.setup()
+        assert abs(U[k] - s.pe) <= 1e-11 * abs(s.pe)
+        assert abs(W[k] - s.virial) <= 1e-9 * max(1.0, abs(s.virial))
+        np.testing.assert_allclose(f[k], s.get_f(), rtol=0, atol=1e-10 * np.abs(s.get_f()).max())
+    e.close()
+
+
+@pytest.mark.gpu
+def test_eam_block_trace_parity(oracle):
+    import neuralmelting_amd as nm
+    mod = 24
+    P, T = grids(2, 2, pr=(1.0, 8.0), tr=(300.0, 900.0))
+    kw = dict(ppos=0.25, pvol=0.25)
+    loop = OracleLoop(oracle, 4, P, T, el='Al', **kw)
+    e = nm.Engine(256, P, T, element='Al', **kw)
+    e.set_state(loop.x, loop.v, loop.box, loop.d)
+    e.set_trace(True)
+    for step in range(2):
+        e.set_step(step)
+        e.run_block(mod)
+        rows = e.thermo()
+        tr = e.trace(mod)
+        for k in range(loop.ns):
+            s = oracle.Sim(256, units=1, mass=lattice.MASS['Al'], pot=1)
+            s.set_rng(256, k, step)
+            out = s.run_block(loop.x[k], loop.v[k], loop.box[k], loop.d[k], mod=mod, nstps=8, bulk=True, ppos=0.25, pvol=0.25,
+                              lat=4.046, t=loop.tq[k], et=loop.et[k], pf=loop.pf[k], trace=True)
+            np.testing.assert_array_equal(tr[k, :, :2], out['trace'][:, :2])
+            np.testing.assert_allclose(tr[k, :, 2], out['trace'][:, 2], rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(rows[k, :5], out['thermo'], rtol=1e-6)
+            np.testing.assert_array_equal(rows[k, 8:14], out['counters'])
+            loop.x[k], loop.v[k], loop.box[k] = out['x'], out['v'], out['box']
+            loop.d[k] = oracle.adapt(out['ratios'], loop.d[k])
+        e.adapt()
+    assert (rows[:, 0] > 100).all()          # kinetic temperatures in kelvin
+    e.close()
