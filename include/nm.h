@@ -104,6 +104,15 @@ int nm_timing_get(nm_ctx *ctx, int *launches, double *total_ms);
 /* per-slot work counters accumulated since the last reset: stats[nslots][NM_STATS_COLS] */
 int nm_stats_get(nm_ctx *ctx, double *stats, int reset);
 
+/* ---- output formatting on the host (write_outputs, remcmc:235-286) ---------------------------------------
+   Byte-identical to the reference's Python formatting: a .thrm row is 17 x ' %.4E' + newline (remcmc:245), a .traj frame is
+   '%d %.4E' % (natoms, box) + newline followed by natoms lines of 3 x ' %.4E' (remcmc:254-256).  No GPU involved. */
+int nm_format_thrm(const double *row17, char *out, int cap);                         /* returns the length written or <0 */
+int nm_format_traj(int natoms, double box, const double *x, char *out, int cap);     /* cap >= 20 + 37*natoms            */
+/* appends one row and one frame to the nk replicas' files, nthreads writer threads (0 = hardware concurrency) */
+int nm_append_outputs(int nk, int natoms, const char *const *thrm_paths, const char *const *traj_paths,
+                      const double *rows, const double *x, const double *box, int nthreads);
+
 /* ---- test-only entry points ------------------------------------------------------------------ */
 /* batched lj_energy_force on the current states: U[nslots], W[nslots] (virial sum r.f), f[nslots][3N] (may be NULL) */
 int nm_eval(nm_ctx *ctx, double *U, double *W, double *f);

@@ -4,6 +4,7 @@
 #include "../../include/nm.h"
 #include "nm_kernels.h"
 #include "nm_distr.h"
+#include "nm_format.h"
 #include "../../include/nm_distr.h"
 
 #include <cmath>
@@ -11,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace nm;
@@ -691,6 +693,53 @@ int nm_distr_histograms(int device, int ns, int natoms, const float *pos, const 
     }
     hipFree(d_pos); hipFree(d_box); hipFree(d_re); hipFree(d_ve); hipFree(d_r); hipFree(d_c);
 #undef DCHK
+    return NM_OK;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// output formatting (include/nm.h; write_outputs, remcmc:235-286): plain host code
+extern "C" {
+
+int nm_format_thrm(const double *row17, char *out, int cap)
+{
+    if (!row17 || !out || cap < 17 * 14 + 2) return NM_ERR_ARG;
+    return format_thrm(row17, out);
+}
+
+int nm_format_traj(int natoms, double box, const double *x, char *out, int cap)
+{
+    if (natoms < 0 || !x || !out || cap < 32 + 42 * natoms) return NM_ERR_ARG;
+    return format_traj(natoms, box, x, out);
+}
+
+int nm_append_outputs(int nk, int natoms, const char *const *thrm_paths, const char *const *traj_paths, const double *rows,
+                      const double *x, const double *box, int nthreads)
+{
+    if (nk < 0 || natoms < 0 || !thrm_paths || !traj_paths || !rows || !x || !box) return NM_ERR_ARG;
+    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > nk) nthreads = nk > 0 ? nk : 1;
+    std::vector<int> err((size_t)nthreads, 0);
+    auto work = [&](int t) {
+        std::vector<char> buf((size_t)64 + 42 * (size_t)natoms + 17 * 14);
+        for (int k = t; k < nk; k += nthreads) {
+            int n = format_thrm(rows + 17 * (size_t)k, buf.data());
+            FILE *f = std::fopen(thrm_paths[k], "a");
+            if (!f || std::fwrite(buf.data(), 1, (size_t)n, f) != (size_t)n) err[t] = 1;
+            if (f) std::fclose(f);
+            n = format_traj(natoms, box[k], x + 3 * (size_t)natoms * k, buf.data());
+            f = std::fopen(traj_paths[k], "a");
+            if (!f || std::fwrite(buf.data(), 1, (size_t)n, f) != (size_t)n) err[t] = 1;
+            if (f) std::fclose(f);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &t : th) t.join();
+    for (int e : err) if (e) return NM_ERR_ARG;
     return NM_OK;
 }
 

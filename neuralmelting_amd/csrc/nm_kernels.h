@@ -18,6 +18,12 @@ constexpr int NVMAX = 12; // widest block reduction (momentum 3 + angular moment
 
 // Diagnostic build only (-DNM_PROF, never the shipped library): shader-clock stamps per section, summed by lane 0
 // of each workgroup into KParams::prof[slot][NM_PROF_SLOTS].
+// NM_DBG(bit): timing experiments that skip work (results are wrong); compiled in only for the diagnostic build
+#ifdef NM_PROF
+#define NM_DBG(bit) (p.dbg & (bit))
+#else
+#define NM_DBG(bit) false
+#endif
 #ifdef NM_PROF
 #define NM_PROF_SLOTS 16
 #define PROF_DECL unsigned long long prof_acc[NM_PROF_SLOTS] = {}; unsigned long long prof_t0 = 0;
@@ -426,7 +432,7 @@ struct Replica {
 #ifdef NM_ENTRY_BARRIER
         __syncthreads();
 #endif
-        if (need || (p.dbg & 4)) __syncthreads();
+        if (need || NM_DBG(4)) __syncthreads();
         else {
             // the list built at (x0, L0) still covers every pair within rc of the affinely rescaled reference if
             // max_i |x_i - (L/L0) x0_i| <= ((L/L0)(rc+skin) - rc)/2
@@ -447,7 +453,7 @@ struct Replica {
 
         double eacc = 0.0, wacc = 0.0, nacc = 0.0;
         PROF_BEGIN();
-        if (p.dbg & 16) { }
+        if (NM_DBG(16)) { }
         else if constexpr (C::POT == 1) { if (want_e) pair_loop_sc<true>(invL, eacc, wacc, nacc); else pair_loop_sc<false>(invL, eacc, wacc, nacc); }
         else if (want_e) pair_loop<true>(invL, eacc, wacc, nacc);
         else pair_loop<false>(invL, eacc, wacc, nacc);
@@ -458,7 +464,7 @@ struct Replica {
         if (want_e) block_sum<3, NW, NVMAX>(s, red, parity); // over this workgroup's atoms
         PROF_END(4);
         PROF_BEGIN();
-        if (Q > 1 && !(p.dbg & 8)) cluster_exchange(want_e, s);
+        if (Q > 1 && !NM_DBG(8)) cluster_exchange(want_e, s);
         else if (!want_e || Q > 1) __syncthreads();
         PROF_END(14);
         PROF_BEGIN();
@@ -485,7 +491,7 @@ struct Replica {
         double a[6] = { 0, 0, 0, 0, 0, 0 };
         for (int i = tid; i < N; i += BLOCK) {
             double nx = vx[i], ny = vy[i], nz = vz[i];
-            if (!(p.dbg & 2)) {
+            if (!NM_DBG(2)) {
                 uint32_t o[4], q[4];
                 philox4x32_10((uint32_t)i, S_VEL_A, tag, p.step, p.seed, (uint32_t)gslot, o);
                 philox4x32_10((uint32_t)i, S_VEL_B, tag, p.step, p.seed, (uint32_t)gslot, q);
@@ -526,7 +532,7 @@ struct Replica {
             s[10] -= m * dy * dz;
             s[11] -= m * dx * dz;
         }
-        if (p.dbg & 1) return;
+        if (NM_DBG(1)) return;
         block_sum<12, NW, NVMAX>(s, red, parity);
         const double e0 = s[0] / mt, e1 = s[1] / mt, e2 = s[2] / mt;
         const double I00 = s[6], I11 = s[7], I22 = s[8], I01 = s[9], I12 = s[10], I02 = s[11];

@@ -153,15 +153,27 @@ class Run:
 
     @staticmethod
     def thrm_text(row):
-        """one .thrm row: 17 x ' %.4E' (remcmc:235-245)"""
-        return 17 * ' %.4E' % tuple(row) + '\n'
+        """one .thrm row: 17 x ' %.4E' (remcmc:235-245), formatted by the library's host-side formatter"""
+        import ctypes as C
+        from . import _lib as B
+        r = np.ascontiguousarray(row, dtype=np.float64)
+        buf = C.create_string_buffer(17 * 14 + 8)
+        n = B.load().nm_format_thrm(r.ctypes.data_as(B.c_double_p), buf, len(buf))
+        if n < 0:
+            raise RuntimeError('nm_format_thrm failed')
+        return buf.raw[:n].decode()
 
     @staticmethod
     def traj_text(natoms, box, x):
         """one .traj frame (remcmc:248-256): 'natoms box' then natoms lines of 3 x ' %.4E'"""
-        x = np.asarray(x).reshape(natoms, 3)
-        body = ''.join([' %.4E %.4E %.4E\n' % (a, b, c) for a, b, c in x])
-        return '%d %.4E\n' % (natoms, box) + body
+        import ctypes as C
+        from . import _lib as B
+        xx = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        buf = C.create_string_buffer(64 + 42 * int(natoms))
+        n = B.load().nm_format_traj(int(natoms), float(box), xx.ctypes.data_as(B.c_double_p), buf, len(buf))
+        if n < 0:
+            raise RuntimeError('nm_format_traj failed')
+        return buf.raw[:n].decode()
 
     def init_outputs(self):
         self.OUTPUT = {k: self.init_output(k) for k in range(self.k0, self.k0 + self.nloc)}
@@ -172,13 +184,19 @@ class Run:
                 f.write(self.header_text(k))
 
     def write_outputs(self, rows, x, box):
-        """write_outputs (remcmc:265-286) for this rank's replicas"""
-        for q in range(self.nloc):
-            thrm, traj = self.OUTPUT[self.k0 + q]
-            with open(thrm, 'a') as f:
-                f.write(self.thrm_text(rows[q]))
-            with open(traj, 'a') as f:
-                f.write(self.traj_text(self.natoms, box[q], x[q]))
+        """write_outputs (remcmc:265-286) for this rank's replicas: one C call formats and appends all files (threaded)"""
+        import ctypes as C
+        from . import _lib as B
+        ks = range(self.k0, self.k0 + self.nloc)
+        thrm = (C.c_char_p * self.nloc)(*[self.OUTPUT[k][0].encode() for k in ks])
+        traj = (C.c_char_p * self.nloc)(*[self.OUTPUT[k][1].encode() for k in ks])
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        box = np.ascontiguousarray(box, dtype=np.float64)
+        rc = B.load().nm_append_outputs(self.nloc, self.natoms, thrm, traj, rows.ctypes.data_as(B.c_double_p),
+                                        x.ctypes.data_as(B.c_double_p), box.ctypes.data_as(B.c_double_p), 0)
+        if rc != 0:
+            raise IOError('nm_append_outputs failed (%d)' % rc)
 
     def consolidate_outputs(self):
         """remcmc:289-316 (rank 0, after every rank finished writing)"""
