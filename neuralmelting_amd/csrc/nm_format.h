@@ -19,7 +19,9 @@ inline int fmt_e4(double v, char *o)
     if (std::signbit(v)) { *q++ = '-'; v = -v; }
     if (std::isinf(v)) { std::memcpy(q, "INF", 3); return (int)(q - o) + 3; }
     if (v == 0.0) { std::memcpy(q, "0.0000E+00", 10); return (int)(q - o) + 10; }
-    int e = (int)std::floor(std::log10(v));
+    int ex;
+    std::frexp(v, &ex);
+    int e = (int)std::floor((ex - 1) * 0.30102999566398120); // within one of floor(log10 v); corrected below
     for (int attempt = 0; attempt < 3; ++attempt) {
         const int k = e - 4; // scaled = v / 10^k should land in [1e4, 1e5)
         if (k < -22 || k > 22) break;
