@@ -59,6 +59,9 @@ typedef struct nm_config {
     double ppos, pvol;   /* PPOS, PVOL (-pm, -vm)                                               */
     const float *P;      /* [np] float32 pressure grid   (remcmc:895)                           */
     const float *T;      /* [nt] float32 temperature grid (remcmc:897)                          */
+    int32_t slot0, nslots; /* optional: an arbitrary range of global slots k = i*nt + j instead of whole rows (nslots > 0
+                              overrides row0/nrows).  A context that holds a partial row cannot run nm_exchange: the sweep
+                              then spans contexts and is done by the host over RCCL (neuralmelting_amd/exchange.py).    */
 } nm_config;
 
 /* life cycle */

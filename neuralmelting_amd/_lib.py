@@ -30,7 +30,8 @@ class NMConfig(C.Structure):
     _fields_ = [('size', C.c_int32), ('element', C.c_int32), ('natoms', C.c_int32), ('np', C.c_int32),
                 ('nt', C.c_int32), ('row0', C.c_int32), ('nrows', C.c_int32), ('nstps', C.c_int32),
                 ('bulk', C.c_int32), ('iter_revert', C.c_int32), ('device', C.c_int32), ('seed', C.c_uint32),
-                ('ppos', C.c_double), ('pvol', C.c_double), ('P', c_float_p), ('T', c_float_p)]
+                ('ppos', C.c_double), ('pvol', C.c_double), ('P', c_float_p), ('T', c_float_p),
+                ('slot0', C.c_int32), ('nslots', C.c_int32)]
 
 
 _lib = None

@@ -46,7 +46,8 @@ struct EvPair { hipEvent_t a, b; bool used; };
 struct nm_ctx {
     nm_config cfg;
     int N, nslots, slot0, kind; // kind: 0 small, 1 mid, 2 large
-    int cus;                    // workgroups per replica (1, 2 or 4; small kernel only)
+    int cus;                    // workgroups per replica
+    bool whole_rows;            // the slot range is made of whole pressure rows (nm_exchange can run on the device)
     double *d_xbuf;
     uint32_t launch_id;
     size_t lds_bytes, aux_doubles;
@@ -176,8 +177,11 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     *out = nullptr;
     if (cfg->size != (int32_t)sizeof(nm_config)) return fail(nullptr, NM_ERR_ARG, "nm_create: nm_config size mismatch (ABI)");
     if (cfg->natoms < 2 || cfg->natoms > 2048) return fail(nullptr, NM_ERR_ARG, "nm_create: natoms must be in [2, 2048]");
-    if (cfg->np < 1 || cfg->nt < 1 || cfg->nrows < 1 || cfg->row0 < 0 || cfg->row0 + cfg->nrows > cfg->np)
-        return fail(nullptr, NM_ERR_ARG, "nm_create: bad grid / row range");
+    const bool by_slots = cfg->nslots > 0;
+    if (cfg->np < 1 || cfg->nt < 1) return fail(nullptr, NM_ERR_ARG, "nm_create: bad grid");
+    if (by_slots ? (cfg->slot0 < 0 || cfg->slot0 + cfg->nslots > cfg->np * cfg->nt)
+                 : (cfg->nrows < 1 || cfg->row0 < 0 || cfg->row0 + cfg->nrows > cfg->np))
+        return fail(nullptr, NM_ERR_ARG, "nm_create: bad row / slot range");
     if (!cfg->P || !cfg->T) return fail(nullptr, NM_ERR_ARG, "nm_create: P and T grids are required");
     if (cfg->nstps < 1 || cfg->ppos < 0 || cfg->pvol < 0 || cfg->ppos + cfg->pvol > 1.0)
         return fail(nullptr, NM_ERR_ARG, "nm_create: bad move parameters");
@@ -194,8 +198,11 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     nm_ctx *c = new nm_ctx();
     c->cfg = *cfg;
     c->N = cfg->natoms;
-    c->nslots = cfg->nrows * cfg->nt;
-    c->slot0 = cfg->row0 * cfg->nt;
+    c->nslots = by_slots ? cfg->nslots : cfg->nrows * cfg->nt;
+    c->slot0 = by_slots ? cfg->slot0 : cfg->row0 * cfg->nt;
+    c->whole_rows = (c->slot0 % cfg->nt == 0) && (c->nslots % cfg->nt == 0);
+    c->cfg.row0 = c->slot0 / cfg->nt;                       // meaningful only for whole rows
+    c->cfg.nrows = c->whole_rows ? c->nslots / cfg->nt : 0;
     c->step = 0;
     c->trace_on = 0; c->trace_mod = 0; c->trace_cap = 0; c->xtape_n = 0;
     c->ev_next = 0; c->launches = 0; c->total_ms = 0.0;
@@ -213,7 +220,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     // init_constant (remcmc:114-132) in float64 on the float32-rounded grid values (NumPy-1.x promotion)
     c->h_et.resize(c->nslots); c->h_pf.resize(c->nslots); c->h_tq.resize(c->nslots);
     for (int k = 0; k < c->nslots; ++k) {
-        const int i = cfg->row0 + k / cfg->nt, j = k % cfg->nt;
+        const int i = (c->slot0 + k) / cfg->nt, j = (c->slot0 + k) % cfg->nt;
         const double Pi = (double)cfg->P[i], Tj = (double)cfg->T[j];
         if (cfg->element == NM_EL_AL) { // remcmc:124-127
             const double kb = 8.61733e-5;
@@ -264,7 +271,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     CHK(dalloc(&c->d_stats, ns * NM_STATS_COLS));
     CHK(dalloc(&c->d_slot2buf, ns)); CHK(dalloc(&c->d_status, ns)); CHK(dalloc(&c->d_nswaps, 1));
     CHK(dalloc(&c->d_evalU, ns)); CHK(dalloc(&c->d_evalW, ns)); CHK(dalloc(&c->d_evalF, ns * n3));
-    const int npairs = cfg->nrows * cfg->nt * (cfg->nt - 1) / 2;
+    const int npairs = c->cfg.nrows * cfg->nt * (cfg->nt - 1) / 2;
     CHK(dalloc(&c->d_xcrit, (size_t)npairs)); CHK(dalloc(&c->d_xtape, (size_t)npairs));
     c->d_prof = nullptr;
 #ifdef NM_PROF
@@ -478,6 +485,8 @@ int nm_adapt(nm_ctx *c)
 int nm_exchange(nm_ctx *c, int *nswaps)
 {
     if (!c) return NM_ERR_ARG;
+    if (!c->whole_rows)
+        return fail(c, NM_ERR_UNSUPPORTED, "nm_exchange: this context holds a partial pressure row; the sweep spans contexts (host exchange over RCCL)");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipMemsetAsync(c->d_nswaps, 0, sizeof(int), c->stream));
     hipLaunchKernelGGL(nm_exchange_kernel, dim3((c->cfg.nrows + 63) / 64), dim3(64), 0, c->stream, c->cfg.nrows, c->cfg.nt,

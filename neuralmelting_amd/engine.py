@@ -24,7 +24,7 @@ class Engine:
     ELEMENTS = {'LJ': B.NM_EL_LJ, 'Al': B.NM_EL_AL}
 
     def __init__(self, natoms, P, T, *, element='LJ', ppos=0.125, pvol=0.125, nstps=8, bulk=True, seed=256,
-                 device=0, row0=0, nrows=None, iter_revert=False):
+                 device=0, row0=0, nrows=None, iter_revert=False, slot0=None, nslots=None):
         self.lib = B.load()
         self._P = np.ascontiguousarray(P, dtype=np.float32)
         self._T = np.ascontiguousarray(T, dtype=np.float32)
@@ -39,6 +39,8 @@ class Engine:
         cfg.nstps, cfg.bulk, cfg.iter_revert = int(nstps), int(bool(bulk)), int(bool(iter_revert))
         cfg.device, cfg.seed = int(device), int(seed)
         cfg.ppos, cfg.pvol = float(ppos), float(pvol)
+        if nslots is not None:  # an arbitrary global slot range (a pressure row split across GPUs)
+            cfg.slot0, cfg.nslots = int(slot0 or 0), int(nslots)
         cfg.P = self._P.ctypes.data_as(B.c_float_p)
         cfg.T = self._T.ctypes.data_as(B.c_float_p)
         h = C.c_void_p()

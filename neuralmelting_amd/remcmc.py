@@ -111,12 +111,19 @@ class Run:
         if LAT[self.EL][0] != 'fcc':
             raise NotImplementedError('only fcc elements are supported')
         self.natoms = 4 * self.SZ ** 3
-        # contiguous pressure rows per rank; the exchange never leaves a row (remcmc:782-798)
-        base, extra = divmod(self.NP, world)
-        self.nrows = base + (1 if rank < extra else 0)
-        self.row0 = rank * base + min(rank, extra)
-        self.k0 = self.row0 * self.NT
-        self.nloc = self.nrows * self.NT
+        # contiguous pressure rows per rank: the exchange never leaves a row (remcmc:782-798), so it stays on the device.
+        # With fewer rows than ranks the slots are dealt out evenly instead and the sweep runs over RCCL (exchange.py).
+        self.split_rows = world > 1 and self.NP < world and self.NS % world == 0
+        if self.split_rows:
+            self.nloc = self.NS // world
+            self.k0 = rank * self.nloc
+            self.row0, self.nrows = self.k0 // self.NT, 0
+        else:
+            base, extra = divmod(self.NP, world)
+            self.nrows = base + (1 if rank < extra else 0)
+            self.row0 = rank * base + min(rank, extra)
+            self.k0 = self.row0 * self.NT
+            self.nloc = self.nrows * self.NT
         self.engine = None
         self.STEP = -1
 
@@ -239,7 +246,7 @@ class Run:
         self.barrier()
         if self.rank == 0:
             full = []
-            for r in range(min(self.world, self.NP)):  # ranks beyond the number of pressure rows hold nothing
+            for r in range(self.world if self.split_rows else min(self.world, self.NP)):  # ranks without rows hold nothing
                 p = rf + '.part%03d.npy' % r
                 full.extend(list(np.load(p, allow_pickle=True)))
                 os.remove(p)
@@ -269,8 +276,34 @@ class Run:
 
     def make_engine(self):
         from .engine import Engine
+        kw = dict(slot0=self.k0, nslots=self.nloc) if self.split_rows else dict(row0=self.row0, nrows=self.nrows)
         return Engine(self.natoms, self.P, self.T, element=self.EL, ppos=self.PPOS, pvol=self.PVOL, nstps=self.NSTPS,
-                      bulk=self.BM, seed=SEED, device=self.device, row0=self.row0, nrows=self.nrows)
+                      bulk=self.BM, seed=SEED, device=self.device, **kw)
+
+    def replica_exchange(self, step):
+        """replica_exchange (remcmc:776-803): on the device when this rank owns whole rows, else all-gather + identical sweep"""
+        eng = self.engine
+        if not self.split_rows:
+            eng.set_step(step)
+            return eng.exchange(count=bool(self.VERBOSE))
+        from . import exchange as X
+        import torch
+        info = (self.world, torch.cuda.is_available())
+        rows = eng.thermo()
+        ev = X.allgather(np.stack([rows[:, 1] + rows[:, 2], rows[:, 4]], axis=1), info)          # (E_tot, V): 16 B per slot
+        et = np.array([init_constant(self.P, self.T, self.EL, *divmod(k, self.NT))[0] for k in range(self.NS)])
+        pf = np.array([init_constant(self.P, self.T, self.EL, *divmod(k, self.NT))[1] for k in range(self.NS)])
+        perm, swaps = X.sweep(self.NP, self.NT, SEED, step, ev[:, 0], ev[:, 1], et, pf)
+        mine = perm[self.k0:self.k0 + self.nloc]
+        if swaps:
+            # entries [0..11] travel (remcmc:798): x, v, box, dx dv dt and the thermo scalars
+            x, v, box, d = eng.get_state()
+            pack = np.concatenate([x, v, box[:, None], d, rows[:, :5]], axis=1)
+            allp = X.allgather(pack, info)[mine]
+            n3 = 3 * self.natoms
+            eng.set_state(allp[:, :n3], allp[:, n3:2 * n3], allp[:, 2 * n3], allp[:, 2 * n3 + 1:2 * n3 + 4])
+            eng.set_thermo(allp[:, 2 * n3 + 4:2 * n3 + 9])
+        return swaps
 
     # ------------------------------------------------------------------ main (remcmc:834-1001)
     def main(self):
@@ -290,13 +323,16 @@ class Run:
             x, v, box, d, th = self.load_samples_restart()
             eng.set_state(x, v, box, d)
             eng.set_thermo(th)
-            eng.set_step(0xFFFFFFFF)  # the exchange after a restart draws from its own counter block
-            n = eng.exchange()
+            n = self.replica_exchange(0xFFFFFFFF)  # the exchange after a restart draws from its own counter block
             self.log('%d replica exchanges performed' % n)
         else:
             self.log('initializing samples')
+            r0 = self.k0 // self.NT                                    # rows covering this rank's slots
+            r1 = (self.k0 + self.nloc - 1) // self.NT
             x, v, box, d = lattice.init_states(self.SZ, self.P, self.T, self.DX, self.DV, el=self.EL, seed=SEED,
-                                               row0=self.row0, nrows=self.nrows, interpolate=self.INTSTS)
+                                               row0=r0, nrows=r1 - r0 + 1, interpolate=self.INTSTS)
+            a = self.k0 - r0 * self.NT
+            x, v, box, d = x[a:a + self.nloc], v[a:a + self.nloc], box[a:a + self.nloc], d[a:a + self.nloc]
             eng.set_state(x, v, box, d)
             if self.INTSTS:
                 eng.set_step(0xFFFFFFFE)
@@ -315,7 +351,7 @@ class Run:
             if (self.STEP + 1) % self.REFREQ == 0:
                 self.dump_samples_restart()               # remcmc:990-992
             if (self.STEP + 1) != self.NSMPL:             # remcmc:994-995
-                n = eng.exchange(count=bool(self.VERBOSE))
+                n = self.replica_exchange(self.STEP)
                 if self.VERBOSE:
                     self.log('%d replica exchanges performed' % n)
         eng.synchronize()

@@ -34,7 +34,7 @@ class OracleLoop:
     """gen_samples / gen_mc_params / replica_exchange on the oracle, holding STATE like the reference does"""
 
     def __init__(self, O, sz, P, T, *, dx=0.03125, dv=0.03125, ppos=0.125, pvol=0.125, nstps=8, bulk=True, seed=256,
-                 row0=0, nrows=None, iter_revert=False, nthreads=0, el='LJ'):
+                 row0=0, nrows=None, iter_revert=False, nthreads=0, el='LJ', k0=None, nk=None):
         self.O = O
         self.P, self.T = P, T
         self.nt = len(T)
@@ -50,6 +50,13 @@ class OracleLoop:
         self.seed = seed
         self.x, self.v, self.box, self.d = lattice.init_states(sz, P, T, dx, dv, el=el, seed=seed, row0=row0, nrows=self.nrows)
         self.et, self.pf, self.tq = (constants_lj if el == 'LJ' else constants_metal)(P, T, row0, self.nrows)
+        self.slot0 = row0 * self.nt
+        if nk is not None:  # an arbitrary slot range inside the covering rows (a pressure row split across ranks)
+            a = k0 - row0 * self.nt
+            sl = slice(a, a + nk)
+            self.x, self.v, self.box, self.d = self.x[sl], self.v[sl], self.box[sl], self.d[sl]
+            self.et, self.pf, self.tq = self.et[sl], self.pf[sl], self.tq[sl]
+            self.ns, self.slot0 = nk, k0
         self.thermo = np.zeros((self.ns, 5))
         self.thermo[:, 4] = self.box ** 3
         self.counters = np.zeros((self.ns, 6))
@@ -57,7 +64,7 @@ class OracleLoop:
 
     def run_block(self, mod, step):
         out = self.O.run_blocks(self.x, self.v, self.box, self.d, self.tq, self.et, self.pf, mod=mod,
-                                slot0=self.row0 * self.nt, step=step, **self.kw)
+                                slot0=self.slot0, step=step, **self.kw)
         self.x, self.v, self.box = out['x'], out['v'], out['box']
         self.thermo, self.counters, self.ratios = out['thermo'], out['counters'], out['ratios']
 
@@ -88,8 +95,15 @@ class OracleEngine:
     def __init__(self, O, run):
         self.O, self.run = O, run
         sz = run.SZ
+        kw = {}
+        if getattr(run, 'split_rows', False):
+            r0 = run.k0 // run.NT
+            r1 = (run.k0 + run.nloc - 1) // run.NT
+            kw = dict(row0=r0, nrows=r1 - r0 + 1, k0=run.k0, nk=run.nloc)
+        else:
+            kw = dict(row0=run.row0, nrows=run.nrows)
         self.loop = OracleLoop(O, sz, run.P, run.T, dx=run.DX, dv=run.DV, ppos=run.PPOS, pvol=run.PVOL, nstps=run.NSTPS,
-                               bulk=run.BM, row0=run.row0, nrows=run.nrows)
+                               bulk=run.BM, **kw)
         self.nslots = self.loop.ns
         self.natoms = self.loop.natoms
         self.step = 0
@@ -122,7 +136,7 @@ class OracleEngine:
         lp = self.loop
         for k in range(lp.ns):
             s = self.O.Sim(lp.natoms)
-            s.set_rng(lp.seed, lp.row0 * lp.nt + k, self.step)
+            s.set_rng(lp.seed, lp.slot0 + k, self.step)
             s.set_box(self.O.q6(lp.box[k])); s.set_x(lp.x[k]); s.set_v(lp.v[k]); s.setup()
             s.velocity_create(self.O.q6(lp.tq[k]), 0); s.zero_linear(); s.zero_angular()
             s.set_timestep(self.O.q6(lp.d[k, 2])); s.setup(); s.run(nsteps)

@@ -33,7 +33,7 @@ def test_header_symbols_are_exported_and_bound():
 def test_config_struct_matches_header():
     from neuralmelting_amd import _lib
     # 12 x int32/uint32, 2 x double, 2 pointers, natural alignment
-    assert C.sizeof(_lib.NMConfig) == 12 * 4 + 2 * 8 + 2 * 8
+    assert C.sizeof(_lib.NMConfig) == 12 * 4 + 2 * 8 + 2 * 8 + 2 * 4
 
 
 def test_product_never_imports_oracle():

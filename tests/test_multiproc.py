@@ -29,9 +29,12 @@ def launch(nproc, cwd, argv):
     subprocess.run(cmd, check=True, timeout=600, env=env, cwd=str(cwd))
 
 
-@pytest.mark.parametrize('npn,world', [(2, 2), (3, 2), (1, 2)])
+@pytest.mark.parametrize('npn,world', [(2, 2), (3, 2), (1, 2)])  # (1, 2): one pressure row split across two ranks
 def test_two_ranks_equal_one_rank(tmp_path, oracle, npn, world):
-    argv = ('-bm -n mp -e LJ -ss 4 -pn %d -tn 2 -sn 2 -sm 4 -rd 1' % npn).split()
+    # the split-row case uses a narrow temperature range so that the sweep does swap replicas across the two ranks
+    argv = ('-bm -n mp -e LJ -ss 4 -pn %d -tn %d -sn 4 -sm 4 -rd 1' % (npn, 4 if npn == 1 else 2)).split()
+    if npn == 1:
+        argv += ['-tr', '1.0', '1.06']
     one = tmp_path / 'one'; two = tmp_path / 'two'
     one.mkdir(); two.mkdir()
     run = remcmc.Run(argv, cwd=str(one))
@@ -42,9 +45,9 @@ def test_two_ranks_equal_one_rank(tmp_path, oracle, npn, world):
         a = open(str(one / ('mp.lj.fcc.lammps' + ext))).read()
         b = open(str(two / ('mp.lj.fcc.lammps' + ext))).read()
         assert a == b                                     # byte-identical consolidated outputs
-    ra = np.load(str(one / 'mp.lj.fcc.lammps.rstrt.0002.npy'), allow_pickle=True)
-    rb = np.load(str(two / 'mp.lj.fcc.lammps.rstrt.0002.npy'), allow_pickle=True)
-    assert ra.shape == rb.shape == (npn * 2, 21)
+    ra = np.load(str(one / 'mp.lj.fcc.lammps.rstrt.0003.npy'), allow_pickle=True)
+    rb = np.load(str(two / 'mp.lj.fcc.lammps.rstrt.0003.npy'), allow_pickle=True)
+    assert ra.shape == rb.shape == (npn * (4 if npn == 1 else 2), 21)
     for sa, sb in zip(ra, rb):
         np.testing.assert_array_equal(sa[1], sb[1])
         assert [float(q) for q in sa[3:]] == [float(q) for q in sb[3:]]
