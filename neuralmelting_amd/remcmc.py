@@ -324,7 +324,8 @@ class Run:
             eng.set_state(x, v, box, d)
             eng.set_thermo(th)
             n = self.replica_exchange(0xFFFFFFFF)  # the exchange after a restart draws from its own counter block
-            self.log('%d replica exchanges performed' % n)
+            if self.VERBOSE:
+                self.log('%d replica exchanges performed' % n)
         else:
             self.log('initializing samples')
             r0 = self.k0 // self.NT                                    # rows covering this rank's slots
