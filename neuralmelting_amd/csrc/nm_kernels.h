@@ -59,6 +59,10 @@ struct Cfg {
     // per-slot global spill when the saved copies do not fit in LDS: sav, savv, x0 (9 NMAX doubles) + images + wrap counts
     static constexpr size_t AUX_DOUBLES = SAVE_LDS ? 0 : (size_t)9 * NMAX + ((size_t)3 * NMAX * 3 + 7) / 8;
     static constexpr size_t NBR_G_ELEMS = LIST_LDS ? 0 : (size_t)MAXNB * NMAX; // per-slot global list
+    // Lists that live in HBM/L2 are stored in chunks of CH consecutive neighbours of one atom ([chunk][atom][CH]) so that one
+    // 8-byte load brings four indices: the dependent L2 round trip per neighbour was the cost there.  LDS lists stay [slot][atom].
+    static constexpr int CH = LIST_LDS ? 1 : 4;
+    static_assert(MAXNB % 4 == 0, "MAXNB must be a multiple of the chunk size");
     static constexpr int QMAX = 8;                                               // most workgroups per replica
     static constexpr size_t XBUF_GRANULES = (size_t)4 * NMAX + 4 * QMAX;         // forces by component, EAM densities, per-workgroup partials
     static constexpr size_t XG_PART = (size_t)3 * NMAX, XG_RHO = (size_t)3 * NMAX + 4 * QMAX; // granule indices
@@ -226,6 +230,13 @@ struct Replica {
     // ------------------------------------------------------------------ Verlet list
     // Wave-cooperative build: one wave per atom i, 64 candidate j per step, ballot compaction keeps the
     // list sorted by j, so the list (and every sum over it) is independent of scheduling.
+    // element index of neighbour slot r of atom i in the list
+    __device__ __forceinline__ size_t nbr_at(int r, int i) const
+    {
+        if constexpr (C::CH == 1) return (size_t)r * NMAX + i;
+        else return ((size_t)(r / C::CH) * NMAX + i) * C::CH + (r % C::CH);
+    }
+
     __device__ void rebuild()
     {
         const int lane = tid & 63, wv = tid >> 6;
@@ -246,7 +257,7 @@ struct Replica {
                 if (in) {
                     const int r = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (r < MAXNB) nbr[(size_t)r * NMAX + i] = (IdxT)j;
+                    if (r < MAXNB) nbr[nbr_at(r, i)] = (IdxT)j;
                 }
                 base += __popcll(m);
             }
@@ -303,12 +314,26 @@ struct Replica {
             if (i < a1) {
                 const double xi = px[i], yi = py[i], zi = pz[i];
                 const int c = cnt[i];
-                for (int s = sub; s < c; s += 2 * TPA) { // two neighbours per trip for instruction-level parallelism
-                    const bool v1 = (s + TPA) < c;
-                    const int j0 = nbr[(size_t)s * NMAX + i];
-                    const int j1 = v1 ? (int)nbr[(size_t)(s + TPA) * NMAX + i] : j0;
-                    pair_one<WANT_E>(j0, xi, yi, zi, invL, rc2, true, ax, ay, az, e, w, np);
-                    pair_one<WANT_E>(j1, xi, yi, zi, invL, rc2, v1, ax, ay, az, e, w, np);
+                if constexpr (C::CH == 1) {
+                    for (int s = sub; s < c; s += 2 * TPA) { // two neighbours per trip for instruction-level parallelism
+                        const bool v1 = (s + TPA) < c;
+                        const int j0 = nbr[(size_t)s * NMAX + i];
+                        const int j1 = v1 ? (int)nbr[(size_t)(s + TPA) * NMAX + i] : j0;
+                        pair_one<WANT_E>(j0, xi, yi, zi, invL, rc2, true, ax, ay, az, e, w, np);
+                        pair_one<WANT_E>(j1, xi, yi, zi, invL, rc2, v1, ax, ay, az, e, w, np);
+                    }
+                } else {
+                    static_assert(sizeof(IdxT) == 2 || C::CH == 1, "chunked lists hold 16-bit indices");
+                    const unsigned long long *nb64 = (const unsigned long long *)nbr;
+                    for (int c0 = sub; c0 * C::CH < c; c0 += TPA) { // one 8-byte load = four neighbours
+                        const unsigned long long wd = nb64[(size_t)c0 * NMAX + i];
+#pragma unroll
+                        for (int q = 0; q < C::CH; ++q) {
+                            const bool ok = (c0 * C::CH + q) < c;
+                            const int j = ok ? (int)((wd >> (16 * q)) & 0xFFFFull) : i; // tail entries of the last chunk are garbage
+                            pair_one<WANT_E>(j, xi, yi, zi, invL, rc2, ok, ax, ay, az, e, w, np);
+                        }
+                    }
                 }
             }
 #pragma unroll

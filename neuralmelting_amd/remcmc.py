@@ -342,12 +342,16 @@ class Run:
                 eng.run_block(0)  # "run 0" of init_sample: thermo scalars of the initial states (remcmc:427)
         self.STEP = -1
         self.dump_samples_restart()
+        pending = None  # a recorded cycle waiting to be written: done while the next block runs on the GPU
         for self.STEP in range(self.NSMPL):
             eng.set_step(self.STEP)
-            eng.run_block(self.MOD)                       # gen_samples
+            eng.run_block(self.MOD)                       # gen_samples (asynchronous)
+            if pending is not None:
+                self.write_outputs(*pending)
+                pending = None
             if (self.STEP + 1) > self.CUTOFF:             # remcmc:983-985
                 xs, _, boxs, _ = eng.get_state()
-                self.write_outputs(eng.thermo(), xs, boxs)
+                pending = (eng.thermo(), xs, boxs)
             eng.adapt()                                   # gen_mc_params
             if (self.STEP + 1) % self.REFREQ == 0:
                 self.dump_samples_restart()               # remcmc:990-992
@@ -355,6 +359,8 @@ class Run:
                 n = self.replica_exchange(self.STEP)
                 if self.VERBOSE:
                     self.log('%d replica exchanges performed' % n)
+        if pending is not None:
+            self.write_outputs(*pending)
         eng.synchronize()
         self.barrier()
         if self.CUTOFF < self.NSMPL and self.rank == 0:
