@@ -24,13 +24,13 @@ namespace {
 #define NM_SMALL_TPA 2
 #endif
 // cluster variants of the small kernel: Q workgroups per replica, threads-per-atom scaled so that all 512 threads work
-typedef Cfg<NM_SMALL_BLOCK, 2 * NM_SMALL_TPA, 256, 160, unsigned char, true, true> CfgSmallQ2;
-typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 160, unsigned char, true, true> CfgSmallQ4;
-typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 160, unsigned char, true, true> CfgSmall;     // N <= 256: everything incl. the byte list in LDS
+typedef Cfg<NM_SMALL_BLOCK, 2 * NM_SMALL_TPA, 256, 192, unsigned char, true, true> CfgSmallQ2;
+typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 192, unsigned char, true, true> CfgSmallQ4;
+typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 192, unsigned char, true, true> CfgSmall;     // N <= 256: everything incl. the byte list in LDS
 // element Al: Sutton-Chen EAM, 4^3 cells only (BASELINE config 4); 200 neighbour slots (134 within rc+skin in the crystal)
-typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 200, unsigned char, true, true, 1> CfgSmallSC;
-typedef Cfg<NM_SMALL_BLOCK, 2 * NM_SMALL_TPA, 256, 200, unsigned char, true, true, 1> CfgSmallSCQ2;
-typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 200, unsigned char, true, true, 1> CfgSmallSCQ4;
+typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 256, unsigned char, true, true, 1> CfgSmallSC;
+typedef Cfg<NM_SMALL_BLOCK, 2 * NM_SMALL_TPA, 256, 256, unsigned char, true, true, 1> CfgSmallSCQ2;
+typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 256, unsigned char, true, true, 1> CfgSmallSCQ4;
 typedef Cfg<512, 1, 864, 160, unsigned short, false, true> CfgMid;     // N <= 864: list in HBM/L2, saved copies in LDS
 typedef Cfg<512, 1, 864, 160, unsigned short, false, true> CfgMidQ2;   // cluster variants: own atoms 432 / 216 / 108
 typedef Cfg<512, 2, 864, 160, unsigned short, false, true> CfgMidQ4;
@@ -63,6 +63,7 @@ struct nm_ctx {
     int *d_tape_off;
     void *d_nbr;
     unsigned long long *d_prof; // diagnostic build only (NM_PROF)
+    unsigned long long *d_tline; // experiment build only
     size_t trace_cap;
     int trace_on, trace_mod;
     int xtape_n;
@@ -111,6 +112,7 @@ void fill_params(const nm_ctx *c, KParams &p)
     p.prof = c->d_prof;
     p.cus = c->cus; p.xbuf = c->d_xbuf; p.launch_id = c->launch_id;
     p.dbg = 0;
+    p.tline = c->d_tline;
     if (const char *e = std::getenv("NM_DBG")) p.dbg = std::atoi(e);
 }
 
@@ -276,6 +278,10 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     const int npairs = c->cfg.nrows * cfg->nt * (cfg->nt - 1) / 2;
     CHK(dalloc(&c->d_xcrit, (size_t)npairs)); CHK(dalloc(&c->d_xtape, (size_t)npairs));
     c->d_prof = nullptr;
+    c->d_tline = nullptr;
+#ifdef NM_EXPERIMENT
+    CHK(dalloc(&c->d_tline, (size_t)8 * 8 * 512 * 8)); CHK(hipMemset(c->d_tline, 0, (size_t)8 * 8 * 512 * 8 * sizeof(unsigned long long)));
+#endif
 #ifdef NM_PROF
     CHK(dalloc(&c->d_prof, ns * 16)); CHK(hipMemset(c->d_prof, 0, ns * 16 * sizeof(unsigned long long)));
 #endif
@@ -325,7 +331,7 @@ int nm_destroy(nm_ctx *c)
     for (auto &e : c->ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     void *ptrs[] = { c->d_x, c->d_v, c->d_box, c->d_steps, c->d_therm, c->d_count, c->d_ratio, c->d_et, c->d_pf, c->d_tq,
                      c->d_stats, c->d_slot2buf, c->d_status, c->d_nswaps, c->d_evalU, c->d_evalW, c->d_evalF, c->d_xcrit,
-                     c->d_xtape, c->d_tape, c->d_tape_off, c->d_trace, c->d_nbr, c->d_aux, c->d_prof, c->d_xbuf };
+                     c->d_xtape, c->d_tape, c->d_tape_off, c->d_trace, c->d_nbr, c->d_aux, c->d_prof, c->d_tline, c->d_xbuf };
     for (void *q : ptrs) if (q) hipFree(q);
     hipStreamDestroy(c->stream);
     delete c;
@@ -538,6 +544,15 @@ int nm_stats_get(nm_ctx *c, double *stats, int reset)
     return NM_OK;
 }
 
+#ifdef NM_EXPERIMENT
+int nm_tline_get(nm_ctx *c, unsigned long long *out)
+{
+    if (!c || !out) return NM_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->d_tline, (size_t)8 * 8 * 512 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return NM_OK;
+}
+#endif
 #ifdef NM_PROF
 // diagnostic build only: cycle sums per section and slot, [nslots][16]
 int nm_prof_get(nm_ctx *c, unsigned long long *out, int reset)

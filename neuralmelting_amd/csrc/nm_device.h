@@ -45,6 +45,7 @@ struct KParams {
     unsigned long long *prof;      // diagnostic build only
     int cus;                       // workgroups (CUs) cooperating on one replica
     int dbg;                       // NM_DBG: timing experiments only (skips work, results are wrong)
+    unsigned long long *tline;     // experiment build only: 100 MHz timestamps of slot 0's evaluations [q][wave][eval][8]
     double *xbuf;                  // [slot][2][XBUF_DOUBLES]: force slices + partial sums exchanged inside a cluster
     uint32_t launch_id;            // distinguishes the granules of successive launches
 };

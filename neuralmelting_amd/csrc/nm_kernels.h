@@ -14,15 +14,26 @@
 
 namespace nm {
 
+#ifndef NM_PAIR_W
+#define NM_PAIR_W 2 // listed neighbours a thread works on at once (pair_vec)
+#endif
 constexpr int NVMAX = 12; // widest block reduction (momentum 3 + angular momentum 3 + inertia 6)
 
 // Diagnostic build only (-DNM_PROF, never the shipped library): shader-clock stamps per section, summed by lane 0
 // of each workgroup into KParams::prof[slot][NM_PROF_SLOTS].
 // NM_DBG(bit): timing experiments that skip work (results are wrong); compiled in only for the diagnostic build
-#ifdef NM_PROF
+#if defined(NM_PROF) || defined(NM_EXPERIMENT)
 #define NM_DBG(bit) (p.dbg & (bit))
 #else
 #define NM_DBG(bit) false
+#endif
+// NM_EXPERIMENT build: TLINE(k) records the constant-rate clock (100 MHz, chip-wide) at point k of an evaluation, per wave, for
+// the workgroups of slot 0 only: lets the phases of one evaluation be laid on a common time axis across the cluster.
+#ifdef NM_EXPERIMENT
+#define TL_EVALS 512
+#define TLINE(k) do { if (tl && tl_n < TL_EVALS && (tid & 63) == 0) tl[((size_t)(q * NW + (tid >> 6)) * TL_EVALS + tl_n) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define TLINE(k) do { } while (0)
 #endif
 #ifdef NM_PROF
 #define NM_PROF_SLOTS 16
@@ -63,6 +74,11 @@ struct Cfg {
     // 8-byte load brings four indices: the dependent L2 round trip per neighbour was the cost there.  LDS lists stay [slot][atom].
     static constexpr int CH = LIST_LDS ? 1 : 4;
     static_assert(MAXNB % 4 == 0, "MAXNB must be a multiple of the chunk size");
+    // LDS byte lists are stored so that the TPA threads of an atom each fetch EIGHT of their neighbours with one conflict-free
+    // ds_read_b64: neighbour slot r of atom i belongs to thread sub = r % TPA as its k-th neighbour (k = r / TPA) and sits at byte
+    // (((k / 8) * NMAX + i) * TPA + sub) * 8 + k % 8.  (One ds_read_u8 per neighbour was an 8-way bank conflict: the 8 threads of
+    // an atom read rows 256 B apart; with the three position gathers it made the pair loop LDS-bound, scripts/ubench_pair.hip.)
+    static_assert(!LIST_LDS || (sizeof(IdxT) == 1 && MAXNB % (8 * TPA) == 0), "LDS lists: bytes, MAXNB a multiple of 8*TPA");
     static constexpr int QMAX = 8;                                               // most workgroups per replica
     static constexpr size_t XBUF_GRANULES = (size_t)4 * NMAX + 4 * QMAX;         // forces by component, EAM densities, per-workgroup partials
     static constexpr size_t XG_PART = (size_t)3 * NMAX, XG_RHO = (size_t)3 * NMAX + 4 * QMAX; // granule indices
@@ -80,6 +96,8 @@ struct Replica {
     const int Q, q, a0, a1;
     double *xb;
     int gen = 0;
+    unsigned long long *tl = nullptr; // experiment build
+    int tl_n = 0;
     double *px, *py, *pz, *vx, *vy, *vz, *fx, *fy, *fz;
     double *sx, *sy, *sz, *svx, *svy, *svz, *x0, *y0, *z0;
     short *im;       // LAMMPS image flags
@@ -103,6 +121,9 @@ struct Replica {
           a1((p_.N * (q_ + 1)) / p_.cus)
     {
         xb = p.xbuf ? p.xbuf + (size_t)slot * 2 * C::XBUF_DOUBLES : nullptr;
+#ifdef NM_EXPERIMENT
+        if (slot == 0) tl = p.tline;
+#endif
         px = (double *)(smem + C::OFF_POS); py = px + NMAX; pz = py + NMAX;
         vx = (double *)(smem + C::OFF_VEL); vy = vx + NMAX; vz = vy + NMAX;
         fx = (double *)(smem + C::OFF_FRC); fy = fx + NMAX; fz = fy + NMAX;
@@ -233,7 +254,7 @@ struct Replica {
     // element index of neighbour slot r of atom i in the list
     __device__ __forceinline__ size_t nbr_at(int r, int i) const
     {
-        if constexpr (C::CH == 1) return (size_t)r * NMAX + i;
+        if constexpr (C::LIST_LDS) { const int sub = r % TPA, k = r / TPA; return ((((size_t)(k >> 3) * NMAX + i) * TPA + sub) << 3) + (k & 7); }
         else return ((size_t)(r / C::CH) * NMAX + i) * C::CH + (r % C::CH);
     }
 
@@ -245,21 +266,30 @@ struct Replica {
         for (int i = a0 + wv; i < a1; i += NW) { // this workgroup's rows of the list
             const double xi = px[i], yi = py[i], zi = pz[i];
             int base = 0;
-            for (int j0 = 0; j0 < N; j0 += 64) {
-                const int j = j0 + lane;
-                bool in = false;
-                if (j < N && j != i) {
-                    double dx = xi - px[j], dy = yi - py[j], dz = zi - pz[j];
-                    dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
-                    in = (dx * dx + dy * dy + dz * dz) < rl2;
+            for (int j0 = 0; j0 < N; j0 += 256) { // four 64-candidate blocks in flight: the distance tests are independent
+                bool in[4];
+                unsigned long long m[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int j = j0 + 64 * b + lane;
+                    in[b] = false;
+                    if (j < N && j != i) {
+                        double dx = xi - px[j], dy = yi - py[j], dz = zi - pz[j];
+                        dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
+                        in[b] = (dx * dx + dy * dy + dz * dz) < rl2;
+                    }
                 }
-                const unsigned long long m = __ballot(in);
-                if (in) {
-                    const int r = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (r < MAXNB) nbr[nbr_at(r, i)] = (IdxT)j;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) m[b] = __ballot(in[b]);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (in[b]) {
+                        const int r = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m[b] >> 32),
+                                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)m[b], 0u));
+                        if (r < MAXNB) nbr[nbr_at(r, i)] = (IdxT)(j0 + 64 * b + lane);
+                    }
+                    base += __popcll(m[b]);
                 }
-                base += __popcll(m);
             }
             if (base > MAXNB) { ovf = 1; base = MAXNB; }
             if (lane == 0) cnt[i] = (unsigned short)base;
@@ -302,6 +332,44 @@ struct Replica {
         }
     }
 
+    // W listed neighbours at once, written stage by stage so that W independent dependency chains interleave (fp64 results
+    // are not available to the next instruction of the same chain for several cycles).
+    template <bool WANT_E, int W>
+    __device__ __forceinline__ void pair_vec(const int (&j)[W], const bool (&ok)[W], double xi, double yi, double zi, double invL,
+                                             double rc2, double &ax, double &ay, double &az, double &e, double &w, double &np)
+    {
+        double dx[W], dy[W], dz[W], r2[W], y[W], t[W], fp[W];
+#pragma unroll
+        for (int q = 0; q < W; ++q) { dx[q] = xi - px[j[q]]; dy[q] = yi - py[j[q]]; dz[q] = zi - pz[j[q]]; }
+#pragma unroll
+        for (int q = 0; q < W; ++q) { dx[q] -= L * rint(dx[q] * invL); dy[q] -= L * rint(dy[q] * invL); dz[q] -= L * rint(dz[q] * invL); }
+#pragma unroll
+        for (int q = 0; q < W; ++q) r2[q] = dx[q] * dx[q] + dy[q] * dy[q] + dz[q] * dz[q];
+#pragma unroll
+        for (int q = 0; q < W; ++q) y[q] = __builtin_amdgcn_rcp(r2[q]);
+#pragma unroll
+        for (int q = 0; q < W; ++q) t[q] = __builtin_fma(-r2[q], y[q], 1.0);
+#pragma unroll
+        for (int q = 0; q < W; ++q) y[q] = __builtin_fma(y[q], t[q], y[q]);
+#pragma unroll
+        for (int q = 0; q < W; ++q) t[q] = __builtin_fma(-r2[q], y[q], 1.0);
+#pragma unroll
+        for (int q = 0; q < W; ++q) y[q] = __builtin_fma(y[q], t[q], y[q]); // 1/r2
+#pragma unroll
+        for (int q = 0; q < W; ++q) t[q] = y[q] * y[q] * y[q];              // 1/r6
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            const bool in = ok[q] && (r2[q] < rc2);
+            fp[q] = in ? t[q] * (48.0 * t[q] - 24.0) * y[q] : 0.0;
+            if (WANT_E) { e += in ? t[q] * (4.0 * t[q] - 4.0) : 0.0; np += in ? 1.0 : 0.0; }
+        }
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            ax += dx[q] * fp[q]; ay += dy[q] * fp[q]; az += dz[q] * fp[q];
+            if (WANT_E) w += r2[q] * fp[q];
+        }
+    }
+
     template <bool WANT_E>
     __device__ __forceinline__ void pair_loop(double invL, double &eacc, double &wacc, double &nacc)
     {
@@ -314,13 +382,25 @@ struct Replica {
             if (i < a1) {
                 const double xi = px[i], yi = py[i], zi = pz[i];
                 const int c = cnt[i];
-                if constexpr (C::CH == 1) {
-                    for (int s = sub; s < c; s += 2 * TPA) { // two neighbours per trip for instruction-level parallelism
-                        const bool v1 = (s + TPA) < c;
-                        const int j0 = nbr[(size_t)s * NMAX + i];
-                        const int j1 = v1 ? (int)nbr[(size_t)(s + TPA) * NMAX + i] : j0;
-                        pair_one<WANT_E>(j0, xi, yi, zi, invL, rc2, true, ax, ay, az, e, w, np);
-                        pair_one<WANT_E>(j1, xi, yi, zi, invL, rc2, v1, ax, ay, az, e, w, np);
+                if constexpr (C::LIST_LDS) {
+                    constexpr int W = NM_PAIR_W;
+                    const unsigned long long *nb64 = (const unsigned long long *)nbr;
+                    const int mine = (c - sub + TPA - 1) / TPA; // neighbours of atom i that this thread handles: slots sub, sub+TPA, ...
+                    for (int k0 = 0; k0 < mine; k0 += 8) {      // one conflict-free 8-byte read = eight of them
+                        const unsigned long long wd = nb64[((size_t)(k0 >> 3) * NMAX + i) * TPA + sub];
+#pragma unroll
+                        for (int e0 = 0; e0 < 8; e0 += W) {
+                            if (k0 + e0 < mine) {
+                                int jj[W];
+                                bool ok[W];
+#pragma unroll
+                                for (int q = 0; q < W; ++q) {
+                                    ok[q] = (k0 + e0 + q) < mine;
+                                    jj[q] = ok[q] ? (int)((wd >> (8 * (e0 + q))) & 0xFFull) : i; // a masked lane looks at itself: finite, ignored
+                                }
+                                pair_vec<WANT_E, W>(jj, ok, xi, yi, zi, invL, rc2, ax, ay, az, e, w, np);
+                            }
+                        }
                     }
                 } else {
                     static_assert(sizeof(IdxT) == 2 || C::CH == 1, "chunked lists hold 16-bit indices");
@@ -438,6 +518,7 @@ struct Replica {
             if (get_granules<1>(gt, mg, v1, timeout)) st |= (int)v1[0];
         }
         ++gen;
+        TLINE(5);
         if (block_any<NW, NVMAX>(timeout != 0, red, parity)) { status |= ST_SYNC_TIMEOUT; return; } // also publishes f to the block
         s[0] = uniform(t0s); s[1] = uniform(t1s); s[2] = uniform(t2s);
         status |= __builtin_amdgcn_readfirstlane(st);
@@ -451,6 +532,7 @@ struct Replica {
         if (!(L >= 2.0 * p.rc)) { status |= ST_BOX_TOO_SMALL; __syncthreads(); return; } // minimum-image limit
         bool need = !list_ok;
         const double invL = 1.0 / L;
+        TLINE(0);
         PROF_BEGIN();
         // The validity check reads only a thread's own atoms (written by itself) and x0 (settled since the last rebuild), so
         // it needs no barrier before it; its own block-wide OR is the barrier that publishes the new positions to everybody.
@@ -472,9 +554,11 @@ struct Replica {
             need = block_any<NW, NVMAX>(bad != 0, red, parity);
         }
         PROF_END(1);
+        TLINE(1);
         PROF_BEGIN();
         if (need) rebuild();
         PROF_END(2);
+        TLINE(2);
 
         double eacc = 0.0, wacc = 0.0, nacc = 0.0;
         PROF_BEGIN();
@@ -483,6 +567,7 @@ struct Replica {
         else if (want_e) pair_loop<true>(invL, eacc, wacc, nacc);
         else pair_loop<false>(invL, eacc, wacc, nacc);
         PROF_END(3);
+        TLINE(3);
         PROF_BEGIN();
         st_evals += 1.0;
         double s[3] = { eacc, wacc, nacc };
@@ -492,6 +577,7 @@ struct Replica {
         if (Q > 1 && !NM_DBG(8)) cluster_exchange(want_e, s);
         else if (!want_e || Q > 1) __syncthreads();
         PROF_END(14);
+        TLINE(4);
         PROF_BEGIN();
         if (want_e) {
             U = 0.5 * s[0]; W = 0.5 * s[1];
@@ -499,6 +585,7 @@ struct Replica {
             if (!(U == U) || isinf(U)) status |= ST_NONFINITE;
         }
         PROF_END(4);
+        ++tl_n;
         fresh = true;
     }
 
@@ -673,8 +760,11 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
         if (i < a1) {
             const double xi = px[i], yi = py[i], zi = pz[i];
             const int c = cnt[i];
-            for (int s = sub; s < c; s += TPA) {
-                const int j = nbr[(size_t)s * NMAX + i];
+            const unsigned long long *nb64 = (const unsigned long long *)nbr;
+            const int mine = (c - sub + TPA - 1) / TPA;
+            for (int k = 0; k < mine; ++k) {
+                const unsigned long long wd = nb64[((size_t)(k >> 3) * NMAX + i) * TPA + sub];
+                const int j = (int)((wd >> (8 * (k & 7))) & 0xFFull);
                 double dx = xi - px[j], dy = yi - py[j], dz = zi - pz[j];
                 dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
                 const double r2 = dx * dx + dy * dy + dz * dz;
@@ -714,8 +804,11 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
         if (i < a1) {
             const double xi = px[i], yi = py[i], zi = pz[i], isi = rho[i];
             const int c = cnt[i];
-            for (int s = sub; s < c; s += TPA) {
-                const int j = nbr[(size_t)s * NMAX + i];
+            const unsigned long long *nb64 = (const unsigned long long *)nbr;
+            const int mine = (c - sub + TPA - 1) / TPA;
+            for (int k = 0; k < mine; ++k) {
+                const unsigned long long wd = nb64[((size_t)(k >> 3) * NMAX + i) * TPA + sub];
+                const int j = (int)((wd >> (8 * (k & 7))) & 0xFFull);
                 double dx = xi - px[j], dy = yi - py[j], dz = zi - pz[j];
                 dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
                 const double r2 = dx * dx + dy * dy + dz * dz;
@@ -771,6 +864,9 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
     const bool writer = (tid == 0 && qq == 0); // one workgroup of the cluster writes the replica's results
     const int N = p.N;
 
+#ifdef NM_EXPERIMENT
+    const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_w0 = wall_clock64();
+#endif
     R.load(buf);
     // init_lammps (remcmc:459-470): change_box %f, scatter x, v, run 0.  nm_eval uses the box as given.
     R.L = uniform(p.eval_only ? p.box[buf] : q6(p.box[buf]));
@@ -938,6 +1034,12 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
         if (!pending) break;
     }
 
+#ifdef NM_EXPERIMENT
+    if (R.tl && tid == 0 && qq == 0) { // shader cycles and 100 MHz ticks of the whole block: the clock the chip held
+        R.tl[(size_t)8 * 8 * 512 * 8 - 2] = __builtin_readcyclecounter() - clk_c0;
+        R.tl[(size_t)8 * 8 * 512 * 8 - 1] = wall_clock64() - clk_w0;
+    }
+#endif
     // lammps_extract (remcmc:377-391) and the acceptance ratios (remcmc:685-688)
     const double smv2 = R.sum_mv2();
     if (qq == 0) R.store(buf);

@@ -1,0 +1,45 @@
+"""dev probe (experiment build): timeline of slot 0's evaluations across its 4 workgroups x 8 waves, 100 MHz clock"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ['NM_HIP_LIB'] = os.path.join(ROOT, 'neuralmelting_amd', 'libnm_hip_exp.so')
+import numpy as np
+import neuralmelting_amd as nm
+from neuralmelting_amd import lattice, _lib
+
+P = np.linspace(1, 8, 8, dtype=np.float32); T = np.linspace(.25, 2.5, 8, dtype=np.float32)
+x, v, box, d = lattice.init_states(4, P, T, 0.03125, 0.03125)
+e = nm.Engine(256, P, T, ppos=0.0, pvol=0.0, nstps=16)
+e.set_state(x, v, box, d)
+for s in range(3):
+    e.set_step(s); e.run_block(24); e.adapt()
+e.synchronize()
+L = _lib.load()
+L.nm_tline_get.argtypes = [C.c_void_p, C.c_void_p]
+buf = np.zeros((8, 8, 512, 8), dtype=np.uint64)   # [q][wave][eval][point]
+L.nm_tline_get(e.h, buf.ctypes.data)
+Q = e.cus_per_replica
+t = buf[:Q].astype(np.int64)
+n = int((t[0, 0, :, 0] > 0).sum())
+print('evals recorded', n, 'Q', Q)
+names = ['entry', 'after check', 'after rebuild', 'pair loop done', 'exchange done(+barrier)', 'granules read']
+ev = range(20, min(n - 1, 400))
+def span(a, b, red=np.max):
+    return np.array([red(t[:, :, k, b]) - np.min(t[:, :, k, a]) for k in ev]) * 10.0   # ns
+print('per evaluation (ns), all 32 waves of the cluster on one axis:')
+print('  first entry -> last wave past check    %7.0f' % np.median(span(0, 1)))
+print('  last check -> last pair loop done      %7.0f' % np.median(np.array([np.max(t[:, :, k, 3]) - np.max(t[:, :, k, 2]) for k in ev]) * 10.0))
+print('  pair loop per wave: median %7.0f  max-over-waves %7.0f  min-over-waves %7.0f' % (
+    np.median((t[:, :, list(ev), 3] - t[:, :, list(ev), 2]) * 10.0),
+    np.median(np.max(t[:, :, list(ev), 3] - t[:, :, list(ev), 2], axis=(0, 1)) * 10.0),
+    np.median(np.min(t[:, :, list(ev), 3] - t[:, :, list(ev), 2], axis=(0, 1)) * 10.0)))
+print('  pair done -> granules read (per wave)  median %7.0f  max %7.0f' % (
+    np.median((t[:, :, list(ev), 5] - t[:, :, list(ev), 3]) * 10.0), np.median(np.max(t[:, :, list(ev), 5] - t[:, :, list(ev), 3], axis=(0, 1)) * 10.0)))
+print('  last pair done -> last exchange done   %7.0f' % np.median(np.array([np.max(t[:, :, k, 4]) - np.max(t[:, :, k, 3]) for k in ev]) * 10.0))
+print('  exchange done -> next entry (kick etc) %7.0f' % np.median(np.array([np.min(t[:, :, k + 1, 0]) - np.max(t[:, :, k, 4]) for k in ev]) * 10.0))
+print('  entry -> next entry                    %7.0f' % np.median(np.array([np.min(t[:, :, k + 1, 0]) - np.min(t[:, :, k, 0]) for k in ev]) * 10.0))
+wg_done = np.array([[np.max(t[q, :, k, 3]) for q in range(Q)] for k in ev])
+print('  skew between workgroups at pair-loop end (max-min) %7.0f' % np.median((wg_done.max(1) - wg_done.min(1)) * 10.0))
+flat = buf.reshape(-1)
+print('shader clock held during the block: %.0f MHz' % (float(flat[-2]) / float(flat[-1]) * 100.0))
+e.close()
