@@ -119,7 +119,7 @@ void fill_params(const nm_ctx *c, KParams &p)
 template <class C>
 hipError_t launch_block(const nm_ctx *c, const KParams &p)
 {
-    hipLaunchKernelGGL(nm_block_kernel<C>, dim3(c->nslots * c->cus), dim3(C::BLOCK), c->lds_bytes, c->stream, p);
+    hipLaunchKernelGGL(nm_block_kernel<C>, dim3(c->nslots * c->cus), dim3(C::BLOCK), C::LDS_BYTES, c->stream, p);
     return hipGetLastError();
 }
 
@@ -239,7 +239,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     }
 
     size_t nbr_elems;
-    if (c->N <= CfgSmall::NMAX) { c->kind = 0; c->lds_bytes = c->pot == 1 ? CfgSmallSC::LDS_BYTES : CfgSmall::LDS_BYTES; c->aux_doubles = CfgSmall::AUX_DOUBLES; nbr_elems = CfgSmall::NBR_G_ELEMS; }
+    if (c->N <= CfgSmall::NMAX) { c->kind = 0; c->lds_bytes = c->pot == 1 ? CfgSmallSC::LDS_BYTES : CfgSmall::LDS_BYTES; /* Q8 variant: set at launch */ c->aux_doubles = CfgSmall::AUX_DOUBLES; nbr_elems = CfgSmall::NBR_G_ELEMS; }
     else if (c->N <= CfgMid::NMAX) { c->kind = 1; c->lds_bytes = CfgMid::LDS_BYTES; c->aux_doubles = CfgMid::AUX_DOUBLES; nbr_elems = CfgMid::NBR_G_ELEMS; }
     else { c->kind = 2; c->lds_bytes = CfgLarge::LDS_BYTES; c->aux_doubles = CfgLarge::AUX_DOUBLES; nbr_elems = CfgLarge::NBR_G_ELEMS; }
 

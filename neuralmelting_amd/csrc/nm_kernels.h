@@ -424,7 +424,7 @@ struct Replica {
             if (i < a1 && sub == 0) {
                 fx[i] = ax; fy[i] = ay; fz[i] = az; eacc += e; wacc += w; nacc += np;
                 if (Q > 1) { // publish this atom's force to the other workgroups of the cluster
-                    const unsigned long long mg = magic();
+                    const unsigned long long mg = magic() ^ ((status & ST_LIST_OVERFLOW) ? POISON : 0ull);
                     put_granule(xg + 2 * (size_t)i, ax, mg);
                     put_granule(xg + 2 * (size_t)(NMAX + i), ay, mg);
                     put_granule(xg + 2 * (size_t)(2 * NMAX + i), az, mg);
@@ -450,6 +450,9 @@ struct Replica {
     // forces of evaluation g to finish g), so buffer g&1 is never overwritten while someone still reads it.  Spins are
     // bounded: a cluster that is not co-resident reports ST_SYNC_TIMEOUT instead of hanging.
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    // a workgroup whose own list overflowed publishes its forces under magic ^ POISON: the peers accept the granule and learn the
+    // status from it (the only status bit that is not identical in all workgroups of a cluster), so no status words are exchanged
+    static constexpr unsigned long long POISON = 0x5555555555555554ull;
     __device__ __forceinline__ unsigned long long magic() const
     {
         return ((unsigned long long)p.launch_id << 32 | (unsigned long long)(uint32_t)(gen + 1)) * 0x9E3779B97F4A7C15ull | 1ull;
@@ -463,9 +466,10 @@ struct Replica {
         // registers may be overwritten (gfx9 hazard), hence the s_nop inside the string
         asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(g), "v"(w) : "memory");
     }
-    // up to three granules per call, issued back to back and waited for once
+    // up to three granules per call, issued back to back and waited for once; `poisoned` is set when a granule carries the
+    // publisher's overflow mark
     template <int K>
-    __device__ __forceinline__ bool get_granules(double *const (&g)[K], unsigned long long mg, double (&out)[K], int &timeout)
+    __device__ __forceinline__ bool get_granules(double *const (&g)[K], unsigned long long mg, double (&out)[K], int &timeout, int &poisoned)
     {
         const unsigned long long t0 = wall_clock64(); // 100 MHz
         for (;;) {
@@ -477,11 +481,17 @@ struct Replica {
             else
                 asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w[0]) : "v"(g[0]) : "memory");
             bool ok = true;
+            int po = 0;
 #pragma unroll
-            for (int k = 0; k < K; ++k) ok = ok && ((w[k].x ^ w[k].y) == mg);
+            for (int k = 0; k < K; ++k) {
+                const unsigned long long x = w[k].x ^ w[k].y;
+                ok = ok && (x == mg || x == (mg ^ POISON));
+                po |= (x == (mg ^ POISON)) ? 1 : 0;
+            }
             if (ok) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) out[k] = __longlong_as_double((long long)w[k].x);
+                poisoned |= po;
                 return true;
             }
             if (wall_clock64() - t0 > 200000000ull) { timeout = 1; return false; } // 2 s
@@ -493,35 +503,35 @@ struct Replica {
     {
         double *xg = xb + (size_t)(gen & 1) * C::XBUF_DOUBLES;
         const unsigned long long mg = magic();
-        if (tid < 4) { // this workgroup's partial sums and status bits
-            const double v = tid == 0 ? s[0] : tid == 1 ? s[1] : tid == 2 ? s[2] : (double)status;
-            put_granule(xg + 2 * (size_t)(C::XG_PART + 4 * q + tid), v, mg);
-        }
-        int timeout = 0;
-        // forces of the atoms the other workgroups own: one thread per atom, three granules in flight
+        if (want_e && tid < 3) put_granule(xg + 2 * (size_t)(C::XG_PART + 4 * q + tid), s[tid == 0 ? 0 : tid == 1 ? 1 : 2], mg); // partial sums
+        int timeout = 0, poisoned = 0;
+        // forces of the atoms the other workgroups own: one thread per atom, three granules in flight, ONE memory round trip
         const int nother = N - (a1 - a0);
         for (int o = tid; o < nother; o += BLOCK) {
             const int i = o < a0 ? o : o + (a1 - a0);
             double *const g3[3] = { xg + 2 * (size_t)i, xg + 2 * (size_t)(NMAX + i), xg + 2 * (size_t)(2 * NMAX + i) };
             double f3[3];
-            if (get_granules<3>(g3, mg, f3, timeout)) { fx[i] = f3[0]; fy[i] = f3[1]; fz[i] = f3[2]; }
+            if (get_granules<3>(g3, mg, f3, timeout, poisoned)) { fx[i] = f3[0]; fy[i] = f3[1]; fz[i] = f3[2]; }
         }
-        // partial sums and status bits in workgroup order (every thread reads them: identical bits everywhere)
+        // partial sums (energy evaluations only): lane r of every wave fetches workgroup r's three sums in one round trip, then the
+        // lanes are added in workgroup order, so every thread of every workgroup ends with the identical bits
         double t0s = 0.0, t1s = 0.0, t2s = 0.0;
-        int st = 0;
-        for (int r = 0; r < Q; ++r) {
-            double *const gs[3] = { xg + 2 * (C::XG_PART + 4 * r), xg + 2 * (C::XG_PART + 4 * r + 1),
-                                    xg + 2 * (C::XG_PART + 4 * r + 2) };
-            double *const gt[1] = { xg + 2 * (C::XG_PART + 4 * r + 3) };
-            double v3[3] = { 0.0, 0.0, 0.0 }, v1[1] = { 0.0 };
-            if (want_e && get_granules<3>(gs, mg, v3, timeout)) { t0s += v3[0]; t1s += v3[1]; t2s += v3[2]; }
-            if (get_granules<1>(gt, mg, v1, timeout)) st |= (int)v1[0];
+        if (want_e) {
+            const int lane = tid & 63;
+            double v3[3] = { 0.0, 0.0, 0.0 };
+            if (lane < Q) {
+                double *const gs[3] = { xg + 2 * (C::XG_PART + 4 * lane), xg + 2 * (C::XG_PART + 4 * lane + 1), xg + 2 * (C::XG_PART + 4 * lane + 2) };
+                int dummy = 0;
+                get_granules<3>(gs, mg, v3, timeout, dummy);
+            }
+            for (int r = 0; r < Q; ++r) { t0s += __shfl(v3[0], r, 64); t1s += __shfl(v3[1], r, 64); t2s += __shfl(v3[2], r, 64); }
         }
         ++gen;
         TLINE(5);
-        if (block_any<NW, NVMAX>(timeout != 0, red, parity)) { status |= ST_SYNC_TIMEOUT; return; } // also publishes f to the block
+        const int fl = block_any2<NW, NVMAX>(timeout != 0, poisoned != 0, red, parity); // the barrier also publishes f to the block
+        if (fl & 1) { status |= ST_SYNC_TIMEOUT; return; }
+        if (fl & 2) status |= ST_LIST_OVERFLOW; // a peer's list overflowed
         s[0] = uniform(t0s); s[1] = uniform(t1s); s[2] = uniform(t2s);
-        status |= __builtin_amdgcn_readfirstlane(st);
     }
 
     // ------------------------------------------------------------------ lj/cut 2.5 energy, forces, virial
@@ -786,7 +796,8 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
             const int i = o < a0 ? o : o + (a1 - a0);
             double *const g1[1] = { xg + 2 * (C::XG_RHO + i) };
             double v1[1];
-            if (get_granules<1>(g1, mg, v1, timeout)) rho[i] = v1[0];
+            int dummy = 0;
+            if (get_granules<1>(g1, mg, v1, timeout, dummy)) rho[i] = v1[0];
         }
     }
     if (block_any<NW, NVMAX>(timeout != 0, red, parity)) { status |= ST_SYNC_TIMEOUT; return; }
@@ -831,9 +842,10 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
         if (i < a1 && sub == 0) {
             fx[i] = ax; fy[i] = ay; fz[i] = az; eacc += e; wacc += w; nacc += np;
             if (Q > 1) {
-                put_granule(xg + 2 * (size_t)i, ax, mg);
-                put_granule(xg + 2 * (size_t)(NMAX + i), ay, mg);
-                put_granule(xg + 2 * (size_t)(2 * NMAX + i), az, mg);
+                const unsigned long long mgf = mg ^ ((status & ST_LIST_OVERFLOW) ? POISON : 0ull);
+                put_granule(xg + 2 * (size_t)i, ax, mgf);
+                put_granule(xg + 2 * (size_t)(NMAX + i), ay, mgf);
+                put_granule(xg + 2 * (size_t)(2 * NMAX + i), az, mgf);
             }
         }
     }
