@@ -301,6 +301,27 @@ struct Replica {
         if (block_any<NW, NVMAX>(ovf != 0, red, parity)) status |= ST_LIST_OVERFLOW;
     }
 
+    // sum over the TPA consecutive lanes of an atom, total in the lane with sub == 0 (the other lanes hold partial garbage).
+    // DPP row shifts (lane l reads lane l+n inside its 16-lane row) instead of ds_bpermute shuffles: no LDS round trips.  Same
+    // summation tree as an xor butterfly (n = TPA/2, ..., 2, 1), hence the same bits.
+    template <int CTRL>
+    __device__ __forceinline__ double dpp_shl(double v)
+    {
+        const long long b = __double_as_longlong(v);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
+    __device__ __forceinline__ double group_sum(double v)
+    {
+        static_assert(TPA <= 16, "an atom's threads must sit inside one 16-lane DPP row");
+        if constexpr (TPA >= 16) v += dpp_shl<0x108>(v); // row_shl:8
+        if constexpr (TPA >= 8) v += dpp_shl<0x104>(v);  // row_shl:4
+        if constexpr (TPA >= 4) v += dpp_shl<0x102>(v);  // row_shl:2
+        if constexpr (TPA >= 2) v += dpp_shl<0x101>(v);  // row_shl:1
+        return v;
+    }
+
     // 1/r2 by v_rcp_f64 + two Newton steps (about 1 ulp) instead of the 12-instruction IEEE division sequence
     __device__ __forceinline__ double recip(double a)
     {
@@ -347,14 +368,18 @@ struct Replica {
         for (int q = 0; q < W; ++q) r2[q] = dx[q] * dx[q] + dy[q] * dy[q] + dz[q] * dz[q];
 #pragma unroll
         for (int q = 0; q < W; ++q) y[q] = __builtin_amdgcn_rcp(r2[q]);
+        // v_rcp_f64 is good to 2^-24.4 (scripts/ubench_rcp.hip): one Newton step gives 2e-15 relative (20 ulp), two give the
+        // correctly rounded quotient.  Energy evaluations take two, the force-only evaluations inside an HMC trajectory one.
 #pragma unroll
         for (int q = 0; q < W; ++q) t[q] = __builtin_fma(-r2[q], y[q], 1.0);
 #pragma unroll
         for (int q = 0; q < W; ++q) y[q] = __builtin_fma(y[q], t[q], y[q]);
+        if (WANT_E) {
 #pragma unroll
-        for (int q = 0; q < W; ++q) t[q] = __builtin_fma(-r2[q], y[q], 1.0);
+            for (int q = 0; q < W; ++q) t[q] = __builtin_fma(-r2[q], y[q], 1.0);
 #pragma unroll
-        for (int q = 0; q < W; ++q) y[q] = __builtin_fma(y[q], t[q], y[q]); // 1/r2
+            for (int q = 0; q < W; ++q) y[q] = __builtin_fma(y[q], t[q], y[q]);
+        } // y = 1/r2
 #pragma unroll
         for (int q = 0; q < W; ++q) t[q] = y[q] * y[q] * y[q];              // 1/r6
 #pragma unroll
@@ -416,11 +441,8 @@ struct Replica {
                     }
                 }
             }
-#pragma unroll
-            for (int off = TPA / 2; off >= 1; off >>= 1) {
-                ax += __shfl_xor(ax, off, 64); ay += __shfl_xor(ay, off, 64); az += __shfl_xor(az, off, 64);
-                if (WANT_E) { e += __shfl_xor(e, off, 64); w += __shfl_xor(w, off, 64); np += __shfl_xor(np, off, 64); }
-            }
+            ax = group_sum(ax); ay = group_sum(ay); az = group_sum(az);
+            if (WANT_E) { e = group_sum(e); w = group_sum(w); np = group_sum(np); }
             if (i < a1 && sub == 0) {
                 fx[i] = ax; fy[i] = ay; fz[i] = az; eacc += e; wacc += w; nacc += np;
                 if (Q > 1) { // publish this atom's force to the other workgroups of the cluster
