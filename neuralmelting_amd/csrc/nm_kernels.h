@@ -364,8 +364,13 @@ struct Replica {
         for (int q = 0; q < W; ++q) { dx[q] = xi - px[j[q]]; dy[q] = yi - py[j[q]]; dz[q] = zi - pz[j[q]]; }
 #pragma unroll
         for (int q = 0; q < W; ++q) { dx[q] -= L * rint(dx[q] * invL); dy[q] -= L * rint(dy[q] * invL); dz[q] -= L * rint(dz[q] * invL); }
+        double msk[W];
 #pragma unroll
-        for (int q = 0; q < W; ++q) r2[q] = dx[q] * dx[q] + dy[q] * dy[q] + dz[q] * dz[q];
+        for (int q = 0; q < W; ++q) {
+            r2[q] = dx[q] * dx[q] + dy[q] * dy[q] + dz[q] * dz[q];
+            msk[q] = (ok[q] && r2[q] < rc2) ? 1.0 : 0.0; // multiplied in below: a select would be turned back into a divergent
+            r2[q] = ok[q] ? r2[q] : 1.0;                  // branch that serialises the W chains; a masked lane (r2 = 0) stays finite
+        }
 #pragma unroll
         for (int q = 0; q < W; ++q) y[q] = __builtin_amdgcn_rcp(r2[q]);
         // v_rcp_f64 is good to 2^-24.4 (scripts/ubench_rcp.hip): one Newton step gives 2e-15 relative (20 ulp), two give the
@@ -384,9 +389,8 @@ struct Replica {
         for (int q = 0; q < W; ++q) t[q] = y[q] * y[q] * y[q];              // 1/r6
 #pragma unroll
         for (int q = 0; q < W; ++q) {
-            const bool in = ok[q] && (r2[q] < rc2);
-            fp[q] = in ? t[q] * (48.0 * t[q] - 24.0) * y[q] : 0.0;
-            if (WANT_E) { e += in ? t[q] * (4.0 * t[q] - 4.0) : 0.0; np += in ? 1.0 : 0.0; }
+            fp[q] = t[q] * (48.0 * t[q] - 24.0) * y[q] * msk[q];
+            if (WANT_E) { e += t[q] * (4.0 * t[q] - 4.0) * msk[q]; np += msk[q]; }
         }
 #pragma unroll
         for (int q = 0; q < W; ++q) {
