@@ -2,13 +2,14 @@
 // adapt / exchange kernels (remcmc:726-745, 776-803) for gfx950.
 //
 // Mapping to the reference (every LAMMPS command the reference issues is re-implemented here):
-//   setup()            "run 0"            remcmc:469,484,496,527,573,588,608,633
-//   eval()             pair_style lj/cut 2.5 energy/force/virial over a Verlet list kept in LDS
-//   bulk_pmc()         bulk_position_mc   remcmc:477-502  (displace_atoms all random ...)
-//   iter_pmc()         iter_position_mc   remcmc:505-549
-//   vmc()              volume_mc          remcmc:552-595  (change_box ... + scaled scatter)
-//   hmc()              hamiltonian_mc     remcmc:598-640  (velocity create/zero, fix nve run NSTPS)
-//   block end          lammps_extract     remcmc:377-391 + ratios remcmc:685-688
+//   Replica::wrap + eval        "run 0"             remcmc:469,484,496,527,573,588,608,633
+//   Replica::eval               pair_style lj/cut 2.5 (or the Al EAM) energy/force/virial over a Verlet list
+//   nm_block_kernel, PH_BULK    bulk_position_mc    remcmc:477-502  (displace_atoms all random ...)
+//   Replica::iter_pmc           iter_position_mc    remcmc:505-549
+//   nm_block_kernel, PH_VMC     volume_mc           remcmc:552-595  (change_box ... + scaled scatter)
+//   nm_block_kernel, PH_HMC_*   hamiltonian_mc      remcmc:598-640  (Replica::hmc_velocities = velocity create/zero; fix nve run NSTPS)
+//   end of nm_block_kernel      lammps_extract      remcmc:377-391 + ratios remcmc:685-688
+//   Replica::cluster_exchange   (no counterpart)    hand-off between the workgroups that share one replica
 #pragma once
 #include "nm_device.h"
 
@@ -572,9 +573,6 @@ struct Replica {
         PROF_BEGIN();
         // The validity check reads only a thread's own atoms (written by itself) and x0 (settled since the last rebuild), so
         // it needs no barrier before it; its own block-wide OR is the barrier that publishes the new positions to everybody.
-#ifdef NM_ENTRY_BARRIER
-        __syncthreads();
-#endif
         if (need || NM_DBG(4)) __syncthreads();
         else {
             // the list built at (x0, L0) still covers every pair within rc of the affinely rescaled reference if
