@@ -26,6 +26,7 @@ namespace {
 // cluster variants of the small kernel: Q workgroups per replica, threads-per-atom scaled so that all 512 threads work
 typedef Cfg<NM_SMALL_BLOCK, 2 * NM_SMALL_TPA, 256, 192, unsigned char, true, true> CfgSmallQ2;
 typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 192, unsigned char, true, true> CfgSmallQ4;
+typedef Cfg<NM_SMALL_BLOCK, 8 * NM_SMALL_TPA, 256, 256, unsigned char, true, true> CfgSmallQ8; // grids of <= 32 replicas
 typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 192, unsigned char, true, true> CfgSmall;     // N <= 256: everything incl. the byte list in LDS
 // element Al: Sutton-Chen EAM, 4^3 cells only (BASELINE config 4); 200 neighbour slots (134 within rc+skin in the crystal)
 typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 256, unsigned char, true, true, 1> CfgSmallSC;
@@ -128,7 +129,7 @@ hipError_t launch_kind(const nm_ctx *c, const KParams &p)
     switch (c->kind) {
     case 0:
         if (c->pot == 1) return c->cus == 4 ? launch_block<CfgSmallSCQ4>(c, p) : c->cus == 2 ? launch_block<CfgSmallSCQ2>(c, p) : launch_block<CfgSmallSC>(c, p);
-        return c->cus == 4 ? launch_block<CfgSmallQ4>(c, p) : c->cus == 2 ? launch_block<CfgSmallQ2>(c, p) : launch_block<CfgSmall>(c, p);
+        return c->cus == 8 ? launch_block<CfgSmallQ8>(c, p) : c->cus == 4 ? launch_block<CfgSmallQ4>(c, p) : c->cus == 2 ? launch_block<CfgSmallQ2>(c, p) : launch_block<CfgSmall>(c, p);
     case 1: return c->cus == 8 ? launch_block<CfgMidQ8>(c, p) : c->cus == 4 ? launch_block<CfgMidQ4>(c, p) : launch_block<CfgMid>(c, p);
     default: return launch_block<CfgLarge>(c, p);
     }
@@ -263,7 +264,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
         const int cu = prop.multiProcessorCount;
         int want = 8;
         if (const char *e = std::getenv("NM_CUS_PER_REPLICA")) want = std::atoi(e);
-        const int maxq = c->kind == 0 ? 4 : c->kind == 1 ? 8 : 2; // own-atom ranges the instantiated thread mappings cover
+        const int maxq = c->kind == 0 ? (c->pot == 0 ? 8 : 4) : c->kind == 1 ? 8 : 2; // own-atom ranges the instantiated thread mappings cover
         for (int qq : { 8, 4, 2 })
             if (qq <= maxq && want >= qq && c->nslots * qq <= cu) { c->cus = qq; break; }
     }
@@ -306,6 +307,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
         CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmall::LDS_BYTES));
         CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallQ2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmall::LDS_BYTES));
         CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallQ4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmall::LDS_BYTES));
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallQ8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmallQ8::LDS_BYTES));
         CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallSC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmallSC::LDS_BYTES));
         CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallSCQ2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmallSC::LDS_BYTES));
         CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallSCQ4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmallSC::LDS_BYTES));
