@@ -24,6 +24,8 @@ SYMBOLS = ('nm_create', 'nm_destroy', 'nm_last_error', 'nm_nslots', 'nm_natoms',
 
 # include/nm_distr.h
 DISTR_SYMBOLS = ('nm_distr_histograms', 'nm_distr_last_error')
+# include/nm_parse.h
+PARSE_SYMBOLS = ('nm_parse_thrm', 'nm_parse_traj', 'nm_parse_last_error')
 
 
 class NMConfig(C.Structure):
@@ -86,5 +88,12 @@ def load():
     L.nm_distr_histograms.argtypes = [C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, C.c_int, c_double_p, C.c_int, c_double_p,
                                       c_float_p, c_float_p]
     L.nm_distr_last_error.restype = C.c_char_p
+    c_long_p = C.POINTER(C.c_long)
+    L.nm_parse_thrm.restype = C.c_int
+    L.nm_parse_thrm.argtypes = [C.c_char_p, c_float_p, C.c_long, c_long_p, C.c_int]
+    L.nm_parse_traj.restype = C.c_int
+    L.nm_parse_traj.argtypes = [C.c_char_p, C.POINTER(C.c_uint16), c_float_p, c_float_p, C.c_long, C.c_long, c_long_p, c_long_p,
+                                C.c_int]
+    L.nm_parse_last_error.restype = C.c_char_p
     _lib = L
     return L

@@ -5,7 +5,9 @@
 #include "nm_kernels.h"
 #include "nm_distr.h"
 #include "nm_format.h"
+#include "nm_parse.h"
 #include "../../include/nm_distr.h"
+#include "../../include/nm_parse.h"
 
 #include <cmath>
 #include <cstdio>
@@ -772,3 +774,31 @@ int nm_append_outputs(int nk, int natoms, const char *const *thrm_paths, const c
 }
 
 } // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// .thrm / .traj reader (include/nm_parse.h; lammps_parse.py:48-49, 88-96)
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+thread_local std::string g_parse_error;
+}
+extern "C" {
+const char *nm_parse_last_error(void) { return g_parse_error.c_str(); }
+
+int nm_parse_thrm(const char *path, float *rows, long cap_rows, long *nrows, int nthreads)
+{
+    if (!path || (rows && cap_rows < 0)) { g_parse_error = "nm_parse_thrm: bad argument"; return NM_ERR_ARG; }
+    try {
+        return nm::parse_thrm(path, rows, cap_rows, nrows, nthreads, g_parse_error) == 0 ? NM_OK : NM_ERR_ARG;
+    } catch (const std::exception &e) { g_parse_error = e.what(); return NM_ERR_ARG; }
+}
+
+int nm_parse_traj(const char *path, uint16_t *natoms, float *box, float *pos, long cap_frames, long cap_posrows, long *nframes,
+                  long *nposrows, int nthreads)
+{
+    if (!path) { g_parse_error = "nm_parse_traj: bad argument"; return NM_ERR_ARG; }
+    try {
+        return nm::parse_traj(path, natoms, box, pos, cap_frames, cap_posrows, nframes, nposrows, nthreads, g_parse_error) == 0
+                   ? NM_OK : NM_ERR_ARG;
+    } catch (const std::exception &e) { g_parse_error = e.what(); return NM_ERR_ARG; }
+}
+}

@@ -28,6 +28,10 @@ def test_header_symbols_are_exported_and_bound():
     assert dsyms == sorted(_lib.DISTR_SYMBOLS)
     for s in dsyms:
         assert hasattr(L, s), s
+    psyms = declared_symbols('nm_parse.h')
+    assert psyms == sorted(_lib.PARSE_SYMBOLS)
+    for s in psyms:
+        assert hasattr(L, s), s
 
 
 def test_config_struct_matches_header():

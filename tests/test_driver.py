@@ -62,6 +62,11 @@ def check_outputs(tmp_path, run, nrec):
     assert np.array_equal(np.load(pref + '.temp.trgt.npy'), run.T)
     cols, natoms, box, x = parse_like_reference(pref, run.NP, run.NT)
     assert cols[0].shape == (run.NP, run.NT, nrec)
+    # the library's reader (include/nm_parse.h) sees the same numbers as the reference's numpy statements
+    from neuralmelting_amd import parse
+    assert np.array_equal(parse.read_thrm(pref + '.thrm'), np.concatenate([c.reshape(-1, 1) for c in cols], 1), equal_nan=True)
+    n2, b2, x2 = parse.read_traj(pref + '.traj')
+    assert np.array_equal(n2, natoms.reshape(-1)) and np.array_equal(b2, box) and np.array_equal(x2, x.reshape(-1, 3))
     assert (natoms == run.natoms).all() and x.shape == (run.NP, run.NT, nrec, run.natoms, 3)
     assert np.isfinite(x).all() and (box > 5.0).all()
     # per-replica files are consolidated and removed (remcmc:314-316)
@@ -100,6 +105,25 @@ def test_driver_end_to_end_gpu(tmp_path):
     argv2 = '-r -rn g1 -rs 4 -bm -n g2 -e LJ -ss 4 -pn 2 -tn 4 -sn 2 -sm 8 -rd 2'.split()
     run2 = run_driver(tmp_path, argv2)
     check_outputs(tmp_path, run2, nrec=2)
+
+
+@pytest.mark.gpu
+def test_pipeline_sampler_parse_distr_gpu(tmp_path, monkeypatch):
+    """run.sh's first three stages (run.sh:7-16) on the build's own modules: sampler -> parse -> distr, file to file"""
+    from neuralmelting_amd import distr, parse
+    monkeypatch.chdir(tmp_path)
+    run = run_driver(tmp_path, '-bm -n p1 -e LJ -ss 4 -pn 2 -tn 2 -sn 3 -sm 8'.split())
+    parse.main(['-n', 'p1', '-e', 'LJ'])
+    distr.main(['-n', 'p1', '-e', 'LJ', '-sb', '32', '-cb', '8'])
+    pref = run.PREF
+    pos = np.load(pref + '.pos.npy')
+    assert pos.shape == (2, 2, 3, 256, 3) and pos.dtype == np.float32
+    pe = np.load(pref + '.pe.npy')
+    assert pe.shape == (2, 2, 3) and (pe < -1000).all()
+    rdf = np.load(pref + '.rdf.npy')
+    assert rdf.shape == (2, 2, 3, 32) and np.isfinite(rdf).all() and rdf[..., -4:].mean() > 0.5    # g(r) -> 1 at L/2
+    assert rdf[..., :7].max() == 0.0                                                                # excluded core
+    assert np.load(pref + '.cdf.npy').shape == (2, 2, 3, 8, 8, 8)
 
 
 @pytest.mark.gpu
