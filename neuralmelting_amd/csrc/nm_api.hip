@@ -685,41 +685,34 @@ int nm_distr_histograms(int device, int ns, int natoms, const float *pos, const 
     DCHK(hipSetDevice(device));
     const int sb = rdf ? sbins : 0, cb = cdf ? cbins : 0;
     const size_t nc = (size_t)cb * cb * cb;
-    const size_t lds = (((size_t)3 * natoms * sizeof(float) + 7) & ~(size_t)7) + (size_t)(sb + cb + 1) * sizeof(double)
+    const int npad = (natoms + 63) & ~63;
+    const size_t lds = (((size_t)3 * (natoms + npad) * sizeof(float) + 7) & ~(size_t)7) + (size_t)(sb + cb + 1) * sizeof(double)
                      + ((size_t)sb + nc) * sizeof(unsigned int);
     if (lds > 160 * 1024) return dfail(NM_ERR_ARG, "nm_distr_histograms: working set exceeds LDS");
+    if (natoms >= 4096) return dfail(NM_ERR_ARG, "nm_distr_histograms: natoms^2 must stay below 2^24 (float32 counts, as in the reference)");
     DCHK(hipFuncSetAttribute((const void *)nm_distr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int chunk = 4096; // samples per launch: bounds device memory (pos 12 N B + counts) for long trajectories
     float *d_pos = nullptr, *d_box = nullptr;
     double *d_re = nullptr, *d_ve = nullptr;
-    unsigned int *d_r = nullptr, *d_c = nullptr;
+    float *d_r = nullptr, *d_c = nullptr;
     const int cs = ns < chunk ? ns : chunk;
     DCHK(hipMalloc((void **)&d_pos, (size_t)cs * natoms * 3 * sizeof(float)));
     DCHK(hipMalloc((void **)&d_box, (size_t)cs * sizeof(float)));
-    if (rdf) { DCHK(hipMalloc((void **)&d_re, sbins * sizeof(double))); DCHK(hipMalloc((void **)&d_r, (size_t)cs * sbins * sizeof(unsigned int)));
+    if (rdf) { DCHK(hipMalloc((void **)&d_re, sbins * sizeof(double))); DCHK(hipMalloc((void **)&d_r, (size_t)cs * sbins * sizeof(float)));
                DCHK(hipMemcpy(d_re, r_edges, sbins * sizeof(double), hipMemcpyHostToDevice)); }
-    if (cdf) { DCHK(hipMalloc((void **)&d_ve, (cbins + 1) * sizeof(double))); DCHK(hipMalloc((void **)&d_c, (size_t)cs * nc * sizeof(unsigned int)));
+    if (cdf) { DCHK(hipMalloc((void **)&d_ve, (cbins + 1) * sizeof(double))); DCHK(hipMalloc((void **)&d_c, (size_t)cs * nc * sizeof(float)));
                DCHK(hipMemcpy(d_ve, rv_edges, (cbins + 1) * sizeof(double), hipMemcpyHostToDevice)); }
-    std::vector<unsigned int> hr, hc;
     for (int s0 = 0; s0 < ns; s0 += cs) {
         const int n = (ns - s0) < cs ? (ns - s0) : cs;
         DCHK(hipMemcpy(d_pos, pos + (size_t)s0 * natoms * 3, (size_t)n * natoms * 3 * sizeof(float), hipMemcpyHostToDevice));
         DCHK(hipMemcpy(d_box, box + s0, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-        if (rdf) DCHK(hipMemset(d_r, 0, (size_t)n * sbins * sizeof(unsigned int)));
-        if (cdf) DCHK(hipMemset(d_c, 0, (size_t)n * nc * sizeof(unsigned int)));
+        if (rdf) DCHK(hipMemset(d_r, 0, (size_t)n * sbins * sizeof(float)));
+        if (cdf) DCHK(hipMemset(d_c, 0, (size_t)n * nc * sizeof(float)));
         hipLaunchKernelGGL(nm_distr_kernel, dim3(n * 27), dim3(DISTR_BLOCK), lds, 0, natoms, d_pos, d_box, sb, d_re, cb, d_ve, d_r, d_c);
         DCHK(hipGetLastError());
         DCHK(hipDeviceSynchronize());
-        if (rdf) {
-            hr.resize((size_t)n * sbins);
-            DCHK(hipMemcpy(hr.data(), d_r, hr.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
-            for (size_t q = 0; q < hr.size(); ++q) rdf[(size_t)s0 * sbins + q] = (float)hr[q];
-        }
-        if (cdf) {
-            hc.resize((size_t)n * nc);
-            DCHK(hipMemcpy(hc.data(), d_c, hc.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
-            for (size_t q = 0; q < hc.size(); ++q) cdf[(size_t)s0 * nc + q] = (float)hc[q];
-        }
+        if (rdf) DCHK(hipMemcpy(rdf + (size_t)s0 * sbins, d_r, (size_t)n * sbins * sizeof(float), hipMemcpyDeviceToHost));
+        if (cdf) DCHK(hipMemcpy(cdf + (size_t)s0 * nc, d_c, (size_t)n * nc * sizeof(float), hipMemcpyDeviceToHost));
     }
     hipFree(d_pos); hipFree(d_box); hipFree(d_re); hipFree(d_ve); hipFree(d_r); hipFree(d_c);
 #undef DCHK
