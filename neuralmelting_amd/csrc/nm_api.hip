@@ -67,6 +67,8 @@ struct nm_ctx {
     void *d_nbr;
     unsigned long long *d_prof; // diagnostic build only (NM_PROF)
     unsigned long long *d_tline; // experiment build only
+    double *h_stage = nullptr;   // pinned host staging area (nm_set_state / nm_get_state)
+    size_t stage_cap = 0;
     size_t trace_cap;
     int trace_on, trace_mod;
     int xtape_n;
@@ -337,6 +339,7 @@ int nm_destroy(nm_ctx *c)
                      c->d_stats, c->d_slot2buf, c->d_status, c->d_nswaps, c->d_evalU, c->d_evalW, c->d_evalF, c->d_xcrit,
                      c->d_xtape, c->d_tape, c->d_tape_off, c->d_trace, c->d_nbr, c->d_aux, c->d_prof, c->d_tline, c->d_xbuf };
     for (void *q : ptrs) if (q) hipFree(q);
+    if (c->h_stage) hipHostFree(c->h_stage);
     hipStreamDestroy(c->stream);
     delete c;
     return NM_OK;
@@ -365,6 +368,19 @@ static int slot_map(nm_ctx *c, std::vector<int> &m)
     return NM_OK;
 }
 
+// pinned staging area of the context (grown on demand): state moves between the caller's arrays and HBM as whole device
+// arrays, one asynchronous copy each on the context's stream and one wait, instead of up to four small copies per replica
+static int stage_reserve(nm_ctx *c, size_t doubles)
+{
+    if (doubles <= c->stage_cap) return NM_OK;
+    if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
+    c->h_stage = nullptr;
+    c->stage_cap = 0;
+    HIPCHK(c, hipHostMalloc((void **)&c->h_stage, doubles * sizeof(double), hipHostMallocDefault));
+    c->stage_cap = doubles;
+    return NM_OK;
+}
+
 int nm_set_state(nm_ctx *c, int k0, int nk, const double *x, const double *v, const double *box, const double *dxdvdt)
 {
     if (!c || k0 < 0 || nk < 0 || k0 + nk > c->nslots) return fail(c, NM_ERR_ARG, "nm_set_state: slot range");
@@ -372,18 +388,34 @@ int nm_set_state(nm_ctx *c, int k0, int nk, const double *x, const double *v, co
     std::vector<int> m;
     int rc = slot_map(c, m);
     if (rc) return rc;
-    const size_t n3 = (size_t)3 * c->N;
-    for (int q = 0; q < nk; ++q) {
-        const int b = m[k0 + q];
-        if (x) HIPCHK(c, hipMemcpy(c->d_x + b * n3, x + q * n3, n3 * sizeof(double), hipMemcpyHostToDevice));
-        if (v) HIPCHK(c, hipMemcpy(c->d_v + b * n3, v + q * n3, n3 * sizeof(double), hipMemcpyHostToDevice));
-        if (box) {
-            HIPCHK(c, hipMemcpy(c->d_box + b, box + q, sizeof(double), hipMemcpyHostToDevice));
-            const double vol = std::pow(box[q], 3.0);
-            HIPCHK(c, hipMemcpy(c->d_therm + 5 * (size_t)b + 4, &vol, sizeof(double), hipMemcpyHostToDevice));
-        }
-        if (dxdvdt) HIPCHK(c, hipMemcpy(c->d_steps + 3 * (size_t)b, dxdvdt + 3 * q, 3 * sizeof(double), hipMemcpyHostToDevice));
+    const size_t n3 = (size_t)3 * c->N, ns = (size_t)c->nslots;
+    const bool all = nk == c->nslots;
+    // a partial range is merged into the device arrays: read them back first (set-up path, not timed)
+    if ((rc = stage_reserve(c, 2 * ns * n3 + 9 * ns))) return rc;
+    double *hx = c->h_stage, *hv = hx + ns * n3, *hb = hv + ns * n3, *hs = hb + ns, *ht = hs + 3 * ns;
+    if (!all) {
+        if (x) HIPCHK(c, hipMemcpyAsync(hx, c->d_x, ns * n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (v) HIPCHK(c, hipMemcpyAsync(hv, c->d_v, ns * n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (box) HIPCHK(c, hipMemcpyAsync(hb, c->d_box, ns * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (dxdvdt) HIPCHK(c, hipMemcpyAsync(hs, c->d_steps, 3 * ns * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
+    if (box) HIPCHK(c, hipMemcpyAsync(ht, c->d_therm, 5 * ns * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int q = 0; q < nk; ++q) {
+        const size_t bq = (size_t)m[k0 + q];
+        if (x) std::memcpy(hx + bq * n3, x + q * n3, n3 * sizeof(double));
+        if (v) std::memcpy(hv + bq * n3, v + q * n3, n3 * sizeof(double));
+        if (box) { hb[bq] = box[q]; ht[5 * bq + 4] = std::pow(box[q], 3.0); }
+        if (dxdvdt) std::memcpy(hs + 3 * bq, dxdvdt + 3 * q, 3 * sizeof(double));
+    }
+    if (x) HIPCHK(c, hipMemcpyAsync(c->d_x, hx, ns * n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (v) HIPCHK(c, hipMemcpyAsync(c->d_v, hv, ns * n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (box) {
+        HIPCHK(c, hipMemcpyAsync(c->d_box, hb, ns * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_therm, ht, 5 * ns * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    if (dxdvdt) HIPCHK(c, hipMemcpyAsync(c->d_steps, hs, 3 * ns * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // the staging area is reused by the next call
     return NM_OK;
 }
 
@@ -406,13 +438,20 @@ int nm_get_state(nm_ctx *c, int k0, int nk, double *x, double *v, double *box, d
     std::vector<int> m;
     int rc = slot_map(c, m);
     if (rc) return rc;
-    const size_t n3 = (size_t)3 * c->N;
+    const size_t n3 = (size_t)3 * c->N, ns = (size_t)c->nslots;
+    if ((rc = stage_reserve(c, 2 * ns * n3 + 9 * ns))) return rc;
+    double *hx = c->h_stage, *hv = hx + ns * n3, *hb = hv + ns * n3, *hs = hb + ns;
+    if (x) HIPCHK(c, hipMemcpyAsync(hx, c->d_x, ns * n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (v) HIPCHK(c, hipMemcpyAsync(hv, c->d_v, ns * n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (box) HIPCHK(c, hipMemcpyAsync(hb, c->d_box, ns * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (dxdvdt) HIPCHK(c, hipMemcpyAsync(hs, c->d_steps, 3 * ns * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int q = 0; q < nk; ++q) {
-        const int b = m[k0 + q];
-        if (x) HIPCHK(c, hipMemcpy(x + q * n3, c->d_x + b * n3, n3 * sizeof(double), hipMemcpyDeviceToHost));
-        if (v) HIPCHK(c, hipMemcpy(v + q * n3, c->d_v + b * n3, n3 * sizeof(double), hipMemcpyDeviceToHost));
-        if (box) HIPCHK(c, hipMemcpy(box + q, c->d_box + b, sizeof(double), hipMemcpyDeviceToHost));
-        if (dxdvdt) HIPCHK(c, hipMemcpy(dxdvdt + 3 * q, c->d_steps + 3 * (size_t)b, 3 * sizeof(double), hipMemcpyDeviceToHost));
+        const size_t bq = (size_t)m[k0 + q];
+        if (x) std::memcpy(x + q * n3, hx + bq * n3, n3 * sizeof(double));
+        if (v) std::memcpy(v + q * n3, hv + bq * n3, n3 * sizeof(double));
+        if (box) box[q] = hb[bq];
+        if (dxdvdt) std::memcpy(dxdvdt + 3 * q, hs + 3 * bq, 3 * sizeof(double));
     }
     return check_status(c);
 }

@@ -95,12 +95,14 @@ class Engine:
         x, v, box, dxdvdt = prep(x, (nk, n3)), prep(v, (nk, n3)), prep(box, (nk,)), prep(dxdvdt, (nk, 3))
         self._chk(self.lib.nm_set_state(self.h, k0, nk, _dp(x), _dp(v), _dp(box), _dp(dxdvdt)))
 
-    def get_state(self, k0=0, nk=None):
+    def get_state(self, k0=0, nk=None, velocities=True):
+        """x, v, box, (dx, dv, dt) of slots [k0, k0+nk); velocities=False skips the copy of v (returned as None)"""
         nk = self.nslots - k0 if nk is None else nk
         n3 = 3 * self.natoms
-        x, v = np.empty((nk, n3)), np.empty((nk, n3))
+        x = np.empty((nk, n3))
+        v = np.empty((nk, n3)) if velocities else None
         box, d = np.empty(nk), np.empty((nk, 3))
-        self._chk(self.lib.nm_get_state(self.h, k0, nk, _dp(x), _dp(v), _dp(box), _dp(d)))
+        self._chk(self.lib.nm_get_state(self.h, k0, nk, _dp(x), _dp(v) if velocities else None, _dp(box), _dp(d)))
         return x, v, box, d
 
     def set_thermo(self, th, k0=0, nk=None):

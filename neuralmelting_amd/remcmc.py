@@ -10,6 +10,7 @@ torch.distributed.run (one process per GPU).
 """
 import argparse
 import os
+import time
 
 import numpy as np
 
@@ -205,16 +206,39 @@ class Run:
         if rc != 0:
             raise IOError('nm_append_outputs failed (%d)' % rc)
 
+    def _write_async(self, rows, x, box):
+        """write a recorded cycle on a helper thread (the C call releases the GIL) while the host drives the next block;
+        cycles are written in order: the previous write is joined first"""
+        import threading
+        self._write_join()
+        self._writer_err = None
+
+        def work():
+            try:
+                self.write_outputs(rows, x, box)
+            except BaseException as e:  # surfaced by the next join
+                self._writer_err = e
+        self._writer = threading.Thread(target=work)
+        self._writer.start()
+
+    def _write_join(self):
+        w = getattr(self, '_writer', None)
+        if w is not None:
+            w.join()
+            self._writer = None
+            if self._writer_err is not None:
+                raise self._writer_err
+
     def consolidate_outputs(self):
         """remcmc:289-316 (rank 0, after every rank finished writing)"""
         thrm = [self.file_prefix(*divmod(k, self.NT)) + '.thrm' for k in range(self.NS)]
         traj = [t.replace('thrm', 'traj') for t in thrm]
+        import shutil
         for ext, files in (('.thrm', thrm), ('.traj', traj)):
-            with open(self.PREF + ext, 'w') as out:
+            with open(self.PREF + ext, 'wb') as out:     # same bytes as the reference's line-by-line copy
                 for k in range(self.NS):
-                    with open(files[k], 'r') as fin:
-                        for line in fin:
-                            out.write(line)
+                    with open(files[k], 'rb') as fin:
+                        shutil.copyfileobj(fin, out, 1 << 22)
         for k in range(self.NS):
             os.remove(thrm[k])
             os.remove(traj[k])
@@ -343,14 +367,16 @@ class Run:
         self.STEP = -1
         self.dump_samples_restart()
         pending = None  # a recorded cycle waiting to be written: done while the next block runs on the GPU
+        eng.synchronize()
+        t_loop = time.perf_counter()
         for self.STEP in range(self.NSMPL):
             eng.set_step(self.STEP)
             eng.run_block(self.MOD)                       # gen_samples (asynchronous)
             if pending is not None:
-                self.write_outputs(*pending)
+                self._write_async(*pending)
                 pending = None
             if (self.STEP + 1) > self.CUTOFF:             # remcmc:983-985
-                xs, _, boxs, _ = eng.get_state()
+                xs, _, boxs, _ = eng.get_state(velocities=False)
                 pending = (eng.thermo(), xs, boxs)
             eng.adapt()                                   # gen_mc_params
             if (self.STEP + 1) % self.REFREQ == 0:
@@ -360,8 +386,14 @@ class Run:
                 if self.VERBOSE:
                     self.log('%d replica exchanges performed' % n)
         if pending is not None:
-            self.write_outputs(*pending)
+            self._write_async(*pending)
+        self._write_join()
         eng.synchronize()
+        self.loop_seconds = time.perf_counter() - t_loop   # the metric's clock: main loop, remcmc:977-995
+        if self.VERBOSE:
+            self.log('main loop: %.3f s, %.0f MC sweeps/s on this rank (%d replicas x %d moves x %d cycles)'
+                     % (self.loop_seconds, self.nloc * self.MOD * self.NSMPL / max(self.loop_seconds, 1e-9), self.nloc, self.MOD,
+                        self.NSMPL))
         self.barrier()
         if self.CUTOFF < self.NSMPL and self.rank == 0:
             self.consolidate_outputs()

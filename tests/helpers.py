@@ -120,7 +120,7 @@ class OracleEngine:
     def set_thermo(self, th, k0=0, nk=None):
         self.loop.thermo = np.array(th, dtype=np.float64).reshape(self.loop.ns, 5)
 
-    def get_state(self, k0=0, nk=None):
+    def get_state(self, k0=0, nk=None, velocities=True):
         lp = self.loop
         return lp.x.copy(), lp.v.copy(), lp.box.copy(), lp.d.copy()
 
