@@ -49,8 +49,16 @@ def main():
     if world > 1 or 'RANK' in os.environ:  # under torch.distributed.run: one rank per GPU over RCCL (also at N=1)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        # NM_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share cards;
+        # RCCL refuses two ranks on one device).  The driver's runs use RCCL.
+        backend = os.environ.get('NM_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            local = local % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend)
 
     import neuralmelting_amd as nm
     from neuralmelting_amd import lattice
@@ -94,7 +102,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
