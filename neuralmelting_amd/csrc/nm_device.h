@@ -132,11 +132,27 @@ __device__ __forceinline__ bool block_any(bool flag, double *red, int &parity)
     return __builtin_amdgcn_readfirstlane(any) != 0;
 }
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Butterfly over the 64 lanes: every lane ends with the bit-identical total (each step adds the partner's partial, and the
+// partner adds this lane's: a + b == b + a).  The four steps inside a 16-lane row are DPP moves (quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror: no LDS round trip), only the two steps across rows go through ds_bpermute.
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v; // xor butterfly: every lane holds the bit-identical total
+    v += dpp_mov<0xB1>(v);  // quad_perm:[1,0,3,2]
+    v += dpp_mov<0x4E>(v);  // quad_perm:[2,3,0,1]
+    v += dpp_mov<0x141>(v); // row_half_mirror: lane i <-> 7-i of its 8 lanes (the other quad's sum)
+    v += dpp_mov<0x140>(v); // row_mirror: lane i <-> 15-i of its row (the other half row's sum)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
 }
 
 // Sum NV values over the workgroup; every thread returns the same bits (fixed order: butterfly inside a

@@ -18,7 +18,7 @@ namespace nm {
 #ifndef NM_PAIR_W
 #define NM_PAIR_W 2 // listed neighbours a thread works on at once (pair_vec)
 #endif
-constexpr int NVMAX = 12; // widest block reduction (momentum 3 + angular momentum 3 + inertia 6)
+constexpr int NVMAX = 16; // widest block reduction (the 16 raw moments of hmc_velocities)
 
 // Diagnostic build only (-DNM_PROF, never the shipped library): shader-clock stamps per section, summed by lane 0
 // of each workgroup into KParams::prof[slot][NM_PROF_SLOTS].
@@ -628,75 +628,78 @@ struct Replica {
     //                                             t with dof = 3N-3: LAMMPS velocity.cpp create(), defaults mom yes rot no)
     // velocity all zero linear                   (again removes the COM momentum, now round-off only)
     // velocity all zero angular                  (omega = I^-1 L about the centre of mass of the unwrapped coordinates)
-    // in three block reductions: {sum m v, sum m X}, {sum m v^2}, {sum m v, L, I}.  L is accumulated with the velocities
-    // before the second COM subtraction: the difference is (sum m d) x v_cm with sum m d = 0 about the centre of mass.
+    // LAMMPS makes four passes with three global sums.  Here: one pass for the gaussians (2N work items over all threads:
+    // item w < N draws (vx, vy) of atom w, item N + w draws vz), ONE block reduction of the 16 raw moments
+    //   sum m v (3), sum m X (3), sum m v.v, sum m X x v (3), sum m (second moments of X) (6),
+    // from which the quantities of the later passes follow algebraically:
+    //   sum m |v - c|^2            = sum m v.v - M |c|^2                       (c = COM velocity, M = total mass)
+    //   L about the COM, scaled    = sc (sum m X x v - M Xc x c)               (Xc = centre of mass)
+    //   I about the COM            = raw second moments - M (|Xc|^2 1 - Xc Xc^T)   (parallel axis)
+    // and one pass that writes v = sc (v - c) - omega x (X - Xc).  The second "zero linear" would subtract the round-off of
+    // sum m v' / M (~1e-17 relative); it is left out.  Differences to the four-pass arithmetic are ~1e-15 relative.
     __device__ void hmc_velocities(double t, uint32_t tag)
     {
         const double twopi = 6.283185307179586476925286766559;
         const double m = p.mass, fac = 1.0 / sqrt(m), mt = m * N;
-        double a[6] = { 0, 0, 0, 0, 0, 0 };
-        for (int i = tid; i < N; i += BLOCK) {
-            double nx = vx[i], ny = vy[i], nz = vz[i];
-            if (!NM_DBG(2)) {
-                uint32_t o[4], q[4];
-                philox4x32_10((uint32_t)i, S_VEL_A, tag, p.step, p.seed, (uint32_t)gslot, o);
-                philox4x32_10((uint32_t)i, S_VEL_B, tag, p.step, p.seed, (uint32_t)gslot, q);
-                const double u1 = u01(o[0], o[1]), u2 = u01(o[2], o[3]), u3 = u01(q[0], q[1]), u4 = u01(q[2], q[3]);
-                const double r1 = sqrt(-2.0 * log(1.0 - u1)), r2 = sqrt(-2.0 * log(1.0 - u3));
-                nx = r1 * cos(twopi * u2) * fac; ny = r1 * sin(twopi * u2) * fac; nz = r2 * cos(twopi * u4) * fac;
+        if (!NM_DBG(2)) {
+            for (int w = tid; w < 2 * N; w += BLOCK) {
+                const int part = w >= N ? 1 : 0, i = w - part * N;
+                uint32_t o[4];
+                philox4x32_10((uint32_t)i, part ? S_VEL_B : S_VEL_A, tag, p.step, p.seed, (uint32_t)gslot, o);
+                const double u1 = u01(o[0], o[1]), u2 = u01(o[2], o[3]);
+                const double r = sqrt(-2.0 * log(1.0 - u1));
+                if (part) vz[i] = r * cos(twopi * u2) * fac;
+                else { vx[i] = r * cos(twopi * u2) * fac; vy[i] = r * sin(twopi * u2) * fac; }
             }
-            vx[i] = nx; vy[i] = ny; vz[i] = nz;
-            a[0] += m * nx; a[1] += m * ny; a[2] += m * nz;
-            a[3] += m * (px[i] + im[3 * i] * L); a[4] += m * (py[i] + im[3 * i + 1] * L); a[5] += m * (pz[i] + im[3 * i + 2] * L);
+            __syncthreads();
         }
-        block_sum<6, NW, NVMAX>(a, red, parity);
-        const double c0 = a[0] / mt, c1 = a[1] / mt, c2 = a[2] / mt;   // COM velocity
-        const double cx = a[3] / mt, cy = a[4] / mt, cz = a[5] / mt;   // centre of mass (unwrapped)
-        double s2[1] = { 0.0 };
+        double a[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = 0.0;
         for (int i = tid; i < N; i += BLOCK) {
-            const double ax = vx[i] - c0, ay = vy[i] - c1, az = vz[i] - c2;
-            vx[i] = ax; vy[i] = ay; vz[i] = az;
-            s2[0] += m * (ax * ax + ay * ay + az * az);
-        }
-        block_sum<1, NW, NVMAX>(s2, red, parity);
-        const double dof = 3.0 * N - 3.0;
-        const double tcur = s2[0] * p.mvv2e / (dof * p.kB);
-        const double sc = sqrt(t / tcur);
-        double s[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // sum m v (3), L (3), I00 I11 I22 I01 I12 I02
-        for (int i = tid; i < N; i += BLOCK) {
-            const double ax = vx[i] * sc, ay = vy[i] * sc, az = vz[i] * sc;
-            vx[i] = ax; vy[i] = ay; vz[i] = az;
-            const double dx = px[i] + im[3 * i] * L - cx, dy = py[i] + im[3 * i + 1] * L - cy, dz = pz[i] + im[3 * i + 2] * L - cz;
-            s[0] += m * ax; s[1] += m * ay; s[2] += m * az;
-            s[3] += m * (dy * az - dz * ay);
-            s[4] += m * (dz * ax - dx * az);
-            s[5] += m * (dx * ay - dy * ax);
-            s[6] += m * (dy * dy + dz * dz);
-            s[7] += m * (dx * dx + dz * dz);
-            s[8] += m * (dx * dx + dy * dy);
-            s[9] -= m * dx * dy;
-            s[10] -= m * dy * dz;
-            s[11] -= m * dx * dz;
+            const double ax = vx[i], ay = vy[i], az = vz[i];
+            const double X = px[i] + im[3 * i] * L, Y = py[i] + im[3 * i + 1] * L, Z = pz[i] + im[3 * i + 2] * L;
+            a[0] += m * ax; a[1] += m * ay; a[2] += m * az;
+            a[3] += m * X; a[4] += m * Y; a[5] += m * Z;
+            a[6] += m * (ax * ax + ay * ay + az * az);
+            a[7] += m * (Y * az - Z * ay);
+            a[8] += m * (Z * ax - X * az);
+            a[9] += m * (X * ay - Y * ax);
+            a[10] += m * (Y * Y + Z * Z);
+            a[11] += m * (X * X + Z * Z);
+            a[12] += m * (X * X + Y * Y);
+            a[13] -= m * X * Y;
+            a[14] -= m * Y * Z;
+            a[15] -= m * X * Z;
         }
         if (NM_DBG(1)) return;
-        block_sum<12, NW, NVMAX>(s, red, parity);
-        const double e0 = s[0] / mt, e1 = s[1] / mt, e2 = s[2] / mt;
-        const double I00 = s[6], I11 = s[7], I22 = s[8], I01 = s[9], I12 = s[10], I02 = s[11];
+        block_sum<16, NW, NVMAX>(a, red, parity);
+        const double c0 = a[0] / mt, c1 = a[1] / mt, c2 = a[2] / mt;   // COM velocity
+        const double cx = a[3] / mt, cy = a[4] / mt, cz = a[5] / mt;   // centre of mass (unwrapped)
+        const double dof = 3.0 * N - 3.0;
+        const double s2 = a[6] - mt * (c0 * c0 + c1 * c1 + c2 * c2);
+        const double tcur = s2 * p.mvv2e / (dof * p.kB);
+        const double sc = sqrt(t / tcur);
+        const double L0_ = sc * (a[7] - mt * (cy * c2 - cz * c1));
+        const double L1_ = sc * (a[8] - mt * (cz * c0 - cx * c2));
+        const double L2_ = sc * (a[9] - mt * (cx * c1 - cy * c0));
+        const double I00 = a[10] - mt * (cy * cy + cz * cz), I11 = a[11] - mt * (cx * cx + cz * cz), I22 = a[12] - mt * (cx * cx + cy * cy);
+        const double I01 = a[13] + mt * cx * cy, I12 = a[14] + mt * cy * cz, I02 = a[15] + mt * cx * cz;
         const double det = I00 * I11 * I22 + I01 * I12 * I02 + I02 * I01 * I12 - I00 * I12 * I12 - I01 * I01 * I22 - I02 * I11 * I02;
         double w0 = 0.0, w1 = 0.0, w2 = 0.0;
         if (det > 0.0) {
             const double i00 = I11 * I22 - I12 * I12, i01 = -(I01 * I22 - I02 * I12), i02 = I01 * I12 - I02 * I11;
             const double i10 = -(I01 * I22 - I12 * I02), i11 = I00 * I22 - I02 * I02, i12 = -(I00 * I12 - I02 * I01);
             const double i20 = I01 * I12 - I11 * I02, i21 = -(I00 * I12 - I01 * I02), i22 = I00 * I11 - I01 * I01;
-            w0 = (i00 * s[3] + i01 * s[4] + i02 * s[5]) / det;
-            w1 = (i10 * s[3] + i11 * s[4] + i12 * s[5]) / det;
-            w2 = (i20 * s[3] + i21 * s[4] + i22 * s[5]) / det;
+            w0 = (i00 * L0_ + i01 * L1_ + i02 * L2_) / det;
+            w1 = (i10 * L0_ + i11 * L1_ + i12 * L2_) / det;
+            w2 = (i20 * L0_ + i21 * L1_ + i22 * L2_) / det;
         }
         for (int i = tid; i < N; i += BLOCK) {
             const double dx = px[i] + im[3 * i] * L - cx, dy = py[i] + im[3 * i + 1] * L - cy, dz = pz[i] + im[3 * i + 2] * L - cz;
-            vx[i] = (vx[i] - e0) - (w1 * dz - w2 * dy);
-            vy[i] = (vy[i] - e1) - (w2 * dx - w0 * dz);
-            vz[i] = (vz[i] - e2) - (w0 * dy - w1 * dx);
+            vx[i] = (vx[i] - c0) * sc - (w1 * dz - w2 * dy);
+            vy[i] = (vy[i] - c1) * sc - (w2 * dx - w0 * dz);
+            vz[i] = (vz[i] - c2) * sc - (w0 * dy - w1 * dx);
         }
     }
 
