@@ -115,6 +115,22 @@ __device__ __forceinline__ int block_any2(bool a, bool b, double *red, int &pari
     return __builtin_amdgcn_readfirstlane(any);
 }
 
+// Workgroup-wide OR of three flags with one barrier (bits 0, 1, 2)
+template <int NW, int NVMAX>
+__device__ __forceinline__ int block_any3(bool a, bool b, bool c, double *red, int &parity)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int *r = (int *)(red + parity * (NW * NVMAX));
+    const unsigned long long ma = __ballot(a), mb = __ballot(b), mc = __ballot(c);
+    if (lane == 0) r[wv] = ((ma != 0ull) ? 1 : 0) | ((mb != 0ull) ? 2 : 0) | ((mc != 0ull) ? 4 : 0);
+    __syncthreads();
+    int any = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) any |= r[w];
+    parity ^= 1;
+    return __builtin_amdgcn_readfirstlane(any);
+}
+
 // Workgroup-wide OR with one barrier: a ballot per wave, one LDS word per wave (HIP's __syncthreads_or funnels all
 // 512 threads through LDS atomics: ~4k cycles per call in this kernel).  Same two-halves trick as block_sum.
 template <int NW, int NVMAX>

@@ -47,6 +47,29 @@ constexpr int NVMAX = 16; // widest block reduction (the 16 raw moments of hmc_v
 #define PROF_END(k) do { } while (0)
 #endif
 
+// The dynamic LDS block of the workgroup.  Arrays inside it are addressed as CONSTANT offsets from this symbol through the empty
+// proxy types below: the compiler then knows the address space (ds_read/ds_write with immediate offsets).  Plain `double *`
+// members pointing into LDS were kept by the compiler as generic 64-bit pointers in scratch memory and dereferenced with
+// flat loads — a scratch round trip in front of every elementwise phase.
+extern __shared__ __align__(16) unsigned char nm_lds[];
+
+template <typename T, size_t OFF>
+struct LdsArr {
+    __device__ __forceinline__ T *ptr() const { return (T *)(nm_lds + OFF); }
+    template <typename I> __device__ __forceinline__ T &operator[](I i) const { return ptr()[i]; }
+    __device__ __forceinline__ operator T *() const { return ptr(); }
+};
+// the same interface over a pointer into global memory (configurations whose saved copies / lists do not fit in LDS)
+template <typename T>
+struct GlobArr {
+    T *g = nullptr;
+    __device__ __forceinline__ T *ptr() const { return g; }
+    template <typename I> __device__ __forceinline__ T &operator[](I i) const { return g[i]; }
+    __device__ __forceinline__ operator T *() const { return g; }
+};
+template <bool LDS, typename T, size_t OFF> struct ArrSel { using type = LdsArr<T, OFF>; };
+template <typename T, size_t OFF> struct ArrSel<false, T, OFF> { using type = GlobArr<T>; };
+
 // NMAX (array stride) and MAXNB (neighbour slots per atom) are compile-time so that every LDS array sits at a
 // constant offset: no address registers are needed for them (with run-time strides the eighteen array bases were
 // spilled to scratch and reloaded inside the pair loop).
@@ -99,17 +122,27 @@ struct Replica {
     int gen = 0;
     unsigned long long *tl = nullptr; // experiment build
     int tl_n = 0;
-    double *px, *py, *pz, *vx, *vy, *vz, *fx, *fy, *fz;
-    double *sx, *sy, *sz, *svx, *svy, *svz, *x0, *y0, *z0;
-    short *im;       // LAMMPS image flags
-    signed char *wn; // wrap counts of the coordinates gathered at the start of an iter-PMC move
-    unsigned short *cnt;
-    IdxT *nbr;
-    double *red;
-    double *rho; // EAM: densities, then 1/sqrt(density)
+    static constexpr size_t A1 = (size_t)C::NMAX * sizeof(double);
+    LdsArr<double, C::OFF_POS> px; LdsArr<double, C::OFF_POS + A1> py; LdsArr<double, C::OFF_POS + 2 * A1> pz;
+    LdsArr<double, C::OFF_VEL> vx; LdsArr<double, C::OFF_VEL + A1> vy; LdsArr<double, C::OFF_VEL + 2 * A1> vz;
+    LdsArr<double, C::OFF_FRC> fx; LdsArr<double, C::OFF_FRC + A1> fy; LdsArr<double, C::OFF_FRC + 2 * A1> fz;
+    // saved positions / velocities, list reference positions, image flags, wrap counts: LDS or the per-workgroup global spill
+    typename ArrSel<C::SAVE_LDS, double, C::OFF_SAV>::type sx; typename ArrSel<C::SAVE_LDS, double, C::OFF_SAV + A1>::type sy;
+    typename ArrSel<C::SAVE_LDS, double, C::OFF_SAV + 2 * A1>::type sz;
+    typename ArrSel<C::SAVE_LDS, double, C::OFF_SAVV>::type svx; typename ArrSel<C::SAVE_LDS, double, C::OFF_SAVV + A1>::type svy;
+    typename ArrSel<C::SAVE_LDS, double, C::OFF_SAVV + 2 * A1>::type svz;
+    typename ArrSel<C::SAVE_LDS, double, C::OFF_X0>::type x0; typename ArrSel<C::SAVE_LDS, double, C::OFF_X0 + A1>::type y0;
+    typename ArrSel<C::SAVE_LDS, double, C::OFF_X0 + 2 * A1>::type z0;
+    typename ArrSel<C::SAVE_LDS, short, C::OFF_IMG>::type im;      // LAMMPS image flags
+    typename ArrSel<C::SAVE_LDS, signed char, C::OFF_WN>::type wn; // wrap counts of the coordinates gathered at the start of an iter-PMC move
+    LdsArr<unsigned short, C::OFF_CNT> cnt;
+    typename ArrSel<C::LIST_LDS, IdxT, C::OFF_NBR>::type nbr;
+    LdsArr<double, C::OFF_RED> red;
+    LdsArr<double, C::OFF_RHO> rho; // EAM: densities, then 1/sqrt(density)
     int parity = 0;
     // block-uniform scalars
     double L = 0.0, L0 = 0.0, U = 0.0, W = 0.0;
+    double psum[3] = { 0.0, 0.0, 0.0 }; // partial (then cluster-wide) sums of the last energy evaluation: 2U, 2W, 2 pairs
     bool list_ok = false, fresh = false;
     int status = 0;
     const double *tape = nullptr;
@@ -117,7 +150,7 @@ struct Replica {
     double st_evals = 0.0, st_rebuilds = 0.0, st_eevals = 0.0, st_pairs = 0.0;
     PROF_DECL
 
-    __device__ Replica(const KParams &p_, unsigned char *smem, int slot, int q_)
+    __device__ Replica(const KParams &p_, int slot, int q_)
         : p(p_), tid(threadIdx.x), N(p_.N), gslot(p_.slot0 + slot), Q(p_.cus), q(q_), a0((p_.N * q_) / p_.cus),
           a1((p_.N * (q_ + 1)) / p_.cus)
     {
@@ -125,25 +158,15 @@ struct Replica {
 #ifdef NM_EXPERIMENT
         if (slot == 0) tl = p.tline;
 #endif
-        px = (double *)(smem + C::OFF_POS); py = px + NMAX; pz = py + NMAX;
-        vx = (double *)(smem + C::OFF_VEL); vy = vx + NMAX; vz = vy + NMAX;
-        fx = (double *)(smem + C::OFF_FRC); fy = fx + NMAX; fz = fy + NMAX;
-        red = (double *)(smem + C::OFF_RED);
-        rho = (double *)(smem + C::OFF_RHO);
-        cnt = (unsigned short *)(smem + C::OFF_CNT);
-        if constexpr (C::SAVE_LDS) {
-            sx = (double *)(smem + C::OFF_SAV); svx = (double *)(smem + C::OFF_SAVV); x0 = (double *)(smem + C::OFF_X0);
-            im = (short *)(smem + C::OFF_IMG);
-            wn = (signed char *)(smem + C::OFF_WN);
-        } else {
+        if constexpr (!C::SAVE_LDS) {
             double *a = p.aux_g + ((size_t)slot * p.cus + q_) * C::AUX_DOUBLES; // one spill area per workgroup
-            sx = a; svx = a + 3 * (size_t)NMAX; x0 = a + 6 * (size_t)NMAX;
-            im = (short *)(a + 9 * (size_t)NMAX);
-            wn = (signed char *)(im + 3 * (size_t)NMAX);
+            sx.g = a; sy.g = a + NMAX; sz.g = a + 2 * (size_t)NMAX;
+            svx.g = a + 3 * (size_t)NMAX; svy.g = a + 4 * (size_t)NMAX; svz.g = a + 5 * (size_t)NMAX;
+            x0.g = a + 6 * (size_t)NMAX; y0.g = a + 7 * (size_t)NMAX; z0.g = a + 8 * (size_t)NMAX;
+            im.g = (short *)(a + 9 * (size_t)NMAX);
+            wn.g = (signed char *)(im.g + 3 * (size_t)NMAX);
         }
-        sy = sx + NMAX; sz = sy + NMAX; svy = svx + NMAX; svz = svy + NMAX; y0 = x0 + NMAX; z0 = y0 + NMAX;
-        if constexpr (C::LIST_LDS) nbr = (IdxT *)(smem + C::OFF_NBR);
-        else nbr = (IdxT *)p.nbr_g + (size_t)slot * C::NBR_G_ELEMS;
+        if constexpr (!C::LIST_LDS) nbr.g = (IdxT *)p.nbr_g + (size_t)slot * C::NBR_G_ELEMS;
         if (p.tape) { tape = p.tape + p.tape_off[slot]; tlen = p.tape_off[slot + 1] - p.tape_off[slot]; }
     }
 
@@ -192,13 +215,18 @@ struct Replica {
         }
         __syncthreads();
     }
+    // every workgroup of a cluster holds all positions; velocities are current only for the atoms it integrates
     __device__ void store(int buf)
     {
         __syncthreads();
         double *gx = p.x + (size_t)buf * 3 * N, *gv = p.v + (size_t)buf * 3 * N;
-        for (int a = tid; a < 3 * N; a += BLOCK) {
+        if (q == 0)
+            for (int a = tid; a < 3 * N; a += BLOCK) {
+                const int i = a / 3, c = a - 3 * i;
+                gx[a] = (c == 0 ? px : c == 1 ? py : pz)[i];
+            }
+        for (int a = 3 * a0 + tid; a < 3 * a1; a += BLOCK) {
             const int i = a / 3, c = a - 3 * i;
-            gx[a] = (c == 0 ? px : c == 1 ? py : pz)[i];
             gv[a] = (c == 0 ? vx : c == 1 ? vy : vz)[i];
         }
     }
@@ -245,6 +273,15 @@ struct Replica {
     {
         double s[1] = { 0.0 };
         for (int i = tid; i < N; i += BLOCK) s[0] += p.mass * (vx[i] * vx[i] + vy[i] * vy[i] + vz[i] * vz[i]);
+        block_sum<1, NW, NVMAX>(s, red, parity);
+        return s[0];
+    }
+
+    // sum over the atoms this workgroup integrates (its velocities of the other atoms go stale during a trajectory)
+    __device__ double own_mv2()
+    {
+        double s[1] = { 0.0 };
+        for (int i = a0 + tid; i < a1; i += BLOCK) s[0] += p.mass * (vx[i] * vx[i] + vy[i] * vy[i] + vz[i] * vz[i]);
         block_sum<1, NW, NVMAX>(s, red, parity);
         return s[0];
     }
@@ -400,12 +437,16 @@ struct Replica {
         }
     }
 
+    // fuse (force-only evaluations inside an HMC trajectory): the lane that holds atom i's force integrates it on the spot —
+    // both half kicks around this evaluation and the drift, same arithmetic as advance_and_share(two) — publishes the NEW
+    // position to the cluster and parks it in f[i] (the force has no other reader); positions themselves stay untouched until
+    // the whole workgroup is through its pair loop.  The peers thus get the positions as early as they used to get forces.
     template <bool WANT_E>
-    __device__ __forceinline__ void pair_loop(double invL, double &eacc, double &wacc, double &nacc)
+    __device__ __forceinline__ void pair_loop(double invL, double &eacc, double &wacc, double &nacc, bool fuse, double dtfm, double h)
     {
+        double *xg = xb ? xb + (size_t)(gen & 1) * C::XBUF_DOUBLES : nullptr;
         const int g = tid / TPA, sub = tid - g * TPA;
         const double rc2 = p.rc * p.rc;
-        double *xg = xb ? xb + (size_t)(gen & 1) * C::XBUF_DOUBLES : nullptr;
         for (int i0 = a0; i0 < a1; i0 += G) { // uniform trip count keeps the shuffles below convergent
             const int i = i0 + g;
             double ax = 0.0, ay = 0.0, az = 0.0, e = 0.0, w = 0.0, np = 0.0;
@@ -414,7 +455,7 @@ struct Replica {
                 const int c = cnt[i];
                 if constexpr (C::LIST_LDS) {
                     constexpr int W = NM_PAIR_W;
-                    const unsigned long long *nb64 = (const unsigned long long *)nbr;
+                    const unsigned long long *nb64 = (const unsigned long long *)nbr.ptr();
                     const int mine = (c - sub + TPA - 1) / TPA; // neighbours of atom i that this thread handles: slots sub, sub+TPA, ...
                     for (int k0 = 0; k0 < mine; k0 += 8) {      // one conflict-free 8-byte read = eight of them
                         const unsigned long long wd = nb64[((size_t)(k0 >> 3) * NMAX + i) * TPA + sub];
@@ -434,7 +475,7 @@ struct Replica {
                     }
                 } else {
                     static_assert(sizeof(IdxT) == 2 || C::CH == 1, "chunked lists hold 16-bit indices");
-                    const unsigned long long *nb64 = (const unsigned long long *)nbr;
+                    const unsigned long long *nb64 = (const unsigned long long *)nbr.ptr();
                     for (int c0 = sub; c0 * C::CH < c; c0 += TPA) { // one 8-byte load = four neighbours
                         const unsigned long long wd = nb64[(size_t)c0 * NMAX + i];
 #pragma unroll
@@ -449,13 +490,20 @@ struct Replica {
             ax = group_sum(ax); ay = group_sum(ay); az = group_sum(az);
             if (WANT_E) { e = group_sum(e); w = group_sum(w); np = group_sum(np); }
             if (i < a1 && sub == 0) {
-                fx[i] = ax; fy[i] = ay; fz[i] = az; eacc += e; wacc += w; nacc += np;
-                if (Q > 1) { // publish this atom's force to the other workgroups of the cluster
-                    const unsigned long long mg = magic() ^ ((status & ST_LIST_OVERFLOW) ? POISON : 0ull);
-                    put_granule(xg + 2 * (size_t)i, ax, mg);
-                    put_granule(xg + 2 * (size_t)(NMAX + i), ay, mg);
-                    put_granule(xg + 2 * (size_t)(2 * NMAX + i), az, mg);
+                eacc += e; wacc += w; nacc += np;
+                if (!WANT_E && fuse) {
+                    double ux = __builtin_fma(dtfm, ax, vx[i]), uy = __builtin_fma(dtfm, ay, vy[i]), uz = __builtin_fma(dtfm, az, vz[i]);
+                    ux = __builtin_fma(dtfm, ax, ux); uy = __builtin_fma(dtfm, ay, uy); uz = __builtin_fma(dtfm, az, uz);
+                    vx[i] = ux; vy[i] = uy; vz[i] = uz;
+                    ax = __builtin_fma(h, ux, px[i]); ay = __builtin_fma(h, uy, py[i]); az = __builtin_fma(h, uz, pz[i]);
+                    if (Q > 1) {
+                        const unsigned long long mgp = my_magic();
+                        put_granule(xg + 2 * (size_t)i, ax, mgp);
+                        put_granule(xg + 2 * (size_t)(NMAX + i), ay, mgp);
+                        put_granule(xg + 2 * (size_t)(2 * NMAX + i), az, mgp);
+                    }
                 }
+                fx[i] = ax; fy[i] = ay; fz[i] = az;
             }
         }
     }
@@ -499,9 +547,15 @@ struct Replica {
     __device__ __forceinline__ bool get_granules(double *const (&g)[K], unsigned long long mg, double (&out)[K], int &timeout, int &poisoned)
     {
         const unsigned long long t0 = wall_clock64(); // 100 MHz
+        int spins = 0;
         for (;;) {
             u64x2 w[K];
-            if constexpr (K == 3)
+            static_assert(K == 1 || K == 3 || K == 4, "granule reads come in ones, threes and fours");
+            if constexpr (K == 4)
+                asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                             "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]) : "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]) : "memory");
+            else if constexpr (K == 3)
                 asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\t"
                              "global_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
                              : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]) : "v"(g[0]), "v"(g[1]), "v"(g[2]) : "memory");
@@ -521,51 +575,154 @@ struct Replica {
                 poisoned |= po;
                 return true;
             }
-            if (wall_clock64() - t0 > 200000000ull) { timeout = 1; return false; } // 2 s
-            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 63) == 0 && wall_clock64() - t0 > 200000000ull) { timeout = 1; return false; } // 2 s
         }
     }
 
-    __device__ void cluster_exchange(bool want_e, double (&s)[3])
+    // What crosses the cluster (Q > 1): every workgroup holds all positions but computes forces for, and integrates, only its
+    // own atoms a0..a1.  So an HMC step exchanges the NEW POSITIONS of the own atoms (advance_and_share), an energy evaluation
+    // exchanges per-workgroup partial sums (exchange_sums), the EAM adds its densities (pair_loop_sc); forces never travel.
+    // Every exchange is all-to-all and takes the next generation number; a workgroup whose list overflowed marks whatever it
+    // publishes next with POISON, and whoever reads it takes over the status bit, so the cluster leaves the block together.
+    __device__ __forceinline__ unsigned long long my_magic() const { return magic() ^ ((status & ST_LIST_OVERFLOW) ? POISON : 0ull); }
+
+    // cluster-wide sums of K per-workgroup partial sums (identical in all threads of the workgroup on entry): lane r of every
+    // wave fetches workgroup r's K granules in one round trip, then the lanes are added in workgroup order, so every thread
+    // of every workgroup ends with the identical bits.  Ends with a barrier.
+    template <int K>
+    __device__ void exchange_sums(double (&s)[K])
     {
+        static_assert(K == 4, "one instantiation: callers pad with zeros");
+        if (Q == 1) return;
         double *xg = xb + (size_t)(gen & 1) * C::XBUF_DOUBLES;
         const unsigned long long mg = magic();
-        if (want_e && tid < 3) put_granule(xg + 2 * (size_t)(C::XG_PART + 4 * q + tid), s[tid == 0 ? 0 : tid == 1 ? 1 : 2], mg); // partial sums
-        int timeout = 0, poisoned = 0;
-        // forces of the atoms the other workgroups own: one thread per atom, three granules in flight, ONE memory round trip
-        const int nother = N - (a1 - a0);
-        for (int o = tid; o < nother; o += BLOCK) {
-            const int i = o < a0 ? o : o + (a1 - a0);
-            double *const g3[3] = { xg + 2 * (size_t)i, xg + 2 * (size_t)(NMAX + i), xg + 2 * (size_t)(2 * NMAX + i) };
-            double f3[3];
-            if (get_granules<3>(g3, mg, f3, timeout, poisoned)) { fx[i] = f3[0]; fy[i] = f3[1]; fz[i] = f3[2]; }
+        if (tid < K) {
+            double mine = s[0];
+#pragma unroll
+            for (int k = 1; k < K; ++k) mine = (tid == k) ? s[k] : mine;
+            put_granule(xg + 2 * (size_t)(C::XG_PART + 4 * q + tid), mine, my_magic());
         }
-        // partial sums (energy evaluations only): lane r of every wave fetches workgroup r's three sums in one round trip, then the
-        // lanes are added in workgroup order, so every thread of every workgroup ends with the identical bits
-        double t0s = 0.0, t1s = 0.0, t2s = 0.0;
-        if (want_e) {
-            const int lane = tid & 63;
-            double v3[3] = { 0.0, 0.0, 0.0 };
-            if (lane < Q) {
-                double *const gs[3] = { xg + 2 * (C::XG_PART + 4 * lane), xg + 2 * (C::XG_PART + 4 * lane + 1), xg + 2 * (C::XG_PART + 4 * lane + 2) };
-                int dummy = 0;
-                get_granules<3>(gs, mg, v3, timeout, dummy);
-            }
-            for (int r = 0; r < Q; ++r) { t0s += __shfl(v3[0], r, 64); t1s += __shfl(v3[1], r, 64); t2s += __shfl(v3[2], r, 64); }
+        int timeout = 0, poisoned = 0;
+        const int lane = tid & 63;
+        double v[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = 0.0;
+        if (lane < Q) {
+            double *gs[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) gs[k] = xg + 2 * (C::XG_PART + 4 * lane + k);
+            get_granules<K>(gs, mg, v, timeout, poisoned);
+        }
+        double t[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            t[k] = 0.0;
+            for (int r = 0; r < Q; ++r) t[k] += __shfl(v[k], r, 64);
         }
         ++gen;
         TLINE(5);
-        const int fl = block_any2<NW, NVMAX>(timeout != 0, poisoned != 0, red, parity); // the barrier also publishes f to the block
-        if (fl & 1) { status |= ST_SYNC_TIMEOUT; return; }
+        const int fl = block_any2<NW, NVMAX>(timeout != 0, poisoned != 0, red, parity);
+        if (fl & 1) status |= ST_SYNC_TIMEOUT;
         if (fl & 2) status |= ST_LIST_OVERFLOW; // a peer's list overflowed
-        s[0] = uniform(t0s); s[1] = uniform(t1s); s[2] = uniform(t2s);
+#pragma unroll
+        for (int k = 0; k < K; ++k) s[k] = uniform(t[k]);
+    }
+
+    // a workgroup that leaves the block on its own finding (list overflow) marks everything its peers could be waiting for
+    // next — position granules of its atoms and its partial sums — so that they leave too instead of timing out
+    __device__ void publish_poison()
+    {
+        double *xg = xb + (size_t)(gen & 1) * C::XBUF_DOUBLES;
+        const unsigned long long mgp = magic() ^ POISON;
+        for (int i = a0 + tid; i < a1; i += BLOCK) {
+            put_granule(xg + 2 * (size_t)i, 0.0, mgp);
+            put_granule(xg + 2 * (size_t)(NMAX + i), 0.0, mgp);
+            put_granule(xg + 2 * (size_t)(2 * NMAX + i), 0.0, mgp);
+        }
+        if (tid < 4) put_granule(xg + 2 * (size_t)(C::XG_PART + 4 * q + tid), 0.0, mgp);
+    }
+
+    // the list-validity test of one atom at (x, y, z)
+    struct ListCheck { double sc, thr2, invL; int bad; };
+    __device__ __forceinline__ void check_begin(ListCheck &c) const
+    {
+        // the list built at (x0, L0) still covers every pair within rc of the affinely rescaled reference if
+        // max_i |x_i - (L/L0) x0_i| <= ((L/L0)(rc+skin) - rc)/2
+        c.sc = L / L0;
+        const double thr = 0.5 * (c.sc * (p.rc + p.skin) - p.rc);
+        c.thr2 = thr * thr;
+        c.invL = 1.0 / L;
+        c.bad = !(thr > 0.0);
+    }
+    __device__ __forceinline__ void check_atom(ListCheck &c, int i, double x, double y, double z) const
+    {
+        double dx = x - c.sc * x0[i], dy = y - c.sc * y0[i], dz = z - c.sc * z0[i];
+        dx -= L * rint(dx * c.invL); dy -= L * rint(dy * c.invL); dz -= L * rint(dz * c.invL);
+        if (dx * dx + dy * dy + dz * dz > c.thr2) c.bad = 1;
+    }
+
+    // One integrator step of the own atoms — v += dtfm f (fix nve initial_integrate), or twice that when the final_integrate of
+    // the previous step is folded in (same arithmetic as two separate half kicks), then x += h v — and the hand-over of their
+    // new positions.  The own atoms' threads publish three granules each; the threads of the following waves fetch the
+    // other workgroups' atoms (one thread per atom, three granules in flight, ONE memory round trip) and write them to LDS.
+    // Every position is tested against the list-validity bound by the thread that writes it, so the one block-wide OR at the
+    // end is the barrier that publishes the positions AND the rebuild decision: the evaluation that follows starts at once.
+    // Requires that no thread of the workgroup still reads positions (the caller's evaluation ended with a barrier).
+    // mode 1: one half kick + drift; 2: two half kicks + drift; 3: the pair loop did it already (fuse): f[] holds the new positions
+    // of the own atoms and they are published.
+    __device__ bool advance_and_share(int mode, double dtfm, double h)
+    {
+        int timeout = 0, poisoned = 0;
+        double *xg = xb ? xb + (size_t)(gen & 1) * C::XBUF_DOUBLES : nullptr;
+        const unsigned long long mg = magic(), mgp = my_magic();
+        // the own atoms first and nothing in their way: the peers are waiting for these granules
+        for (int i = a0 + tid; i < a1; i += BLOCK) {
+            const double gx = fx[i], gy = fy[i], gz = fz[i];
+            if (mode == 3) { px[i] = gx; py[i] = gy; pz[i] = gz; continue; }
+            double ux = __builtin_fma(dtfm, gx, vx[i]), uy = __builtin_fma(dtfm, gy, vy[i]), uz = __builtin_fma(dtfm, gz, vz[i]);
+            if (mode == 2) { ux = __builtin_fma(dtfm, gx, ux); uy = __builtin_fma(dtfm, gy, uy); uz = __builtin_fma(dtfm, gz, uz); }
+            vx[i] = ux; vy[i] = uy; vz[i] = uz;
+            const double nx = __builtin_fma(h, ux, px[i]), ny = __builtin_fma(h, uy, py[i]), nz = __builtin_fma(h, uz, pz[i]);
+            px[i] = nx; py[i] = ny; pz[i] = nz;
+            if (Q > 1) {
+                put_granule(xg + 2 * (size_t)i, nx, mgp);
+                put_granule(xg + 2 * (size_t)(NMAX + i), ny, mgp);
+                put_granule(xg + 2 * (size_t)(2 * NMAX + i), nz, mgp);
+            }
+        }
+        ListCheck c;
+        check_begin(c);
+        for (int i = a0 + tid; i < a1; i += BLOCK) check_atom(c, i, px[i], py[i], pz[i]);
+        if (Q > 1) {
+            const int nown = a1 - a0, nother = N - nown;
+            const int shift = ((nown + 63) & ~63) % BLOCK; // the fetching starts on the waves after the ones that integrate
+            for (int o = (tid + BLOCK - shift) % BLOCK; o < nother; o += BLOCK) {
+                const int i = o < a0 ? o : o + nown;
+                double *const g3[3] = { xg + 2 * (size_t)i, xg + 2 * (size_t)(NMAX + i), xg + 2 * (size_t)(2 * NMAX + i) };
+                double x3[3];
+                if (get_granules<3>(g3, mg, x3, timeout, poisoned)) {
+                    px[i] = x3[0]; py[i] = x3[1]; pz[i] = x3[2];
+                    check_atom(c, i, x3[0], x3[1], x3[2]);
+                }
+            }
+            ++gen;
+        }
+        fresh = false;
+        const int fl = block_any3<NW, NVMAX>(timeout != 0, poisoned != 0, c.bad != 0, red, parity);
+        if (fl & 1) status |= ST_SYNC_TIMEOUT;
+        if (fl & 2) status |= ST_LIST_OVERFLOW;
+        return (fl & 4) != 0;
     }
 
     // ------------------------------------------------------------------ lj/cut 2.5 energy, forces, virial
     // pair_lj_cut: r2inv, r6inv, fpair = r6inv*(48 r6inv - 24)*r2inv, evdwl = r6inv*(4 r6inv - 4), no shift/tail.
     // Full (both-direction) list: thread group (i, sub) owns f_i, no scatter, no atomics, fixed summation order.
-    __device__ void eval(bool want_e)
+    // have_need: the caller already holds the rebuild decision for the current positions (advance_and_share) and the barrier
+    // that goes with it.  An energy evaluation leaves this workgroup's partial sums in psum[]; finish_sums() makes U, W of them
+    // (across the cluster, together with one more partial sum of the caller: the kinetic energy at the end of a trajectory).
+    __device__ void eval(bool want_e, bool have_need = false, bool pre_need = false, bool fuse = false, double dtfm = 0.0, double h = 0.0)
     {
+        if (status & (ST_SYNC_TIMEOUT | ST_LIST_OVERFLOW)) return; // learnt from the last hand-over: the cluster is leaving
         if (!(L >= 2.0 * p.rc)) { status |= ST_BOX_TOO_SMALL; __syncthreads(); return; } // minimum-image limit
         bool need = !list_ok;
         const double invL = 1.0 / L;
@@ -573,19 +730,13 @@ struct Replica {
         PROF_BEGIN();
         // The validity check reads only a thread's own atoms (written by itself) and x0 (settled since the last rebuild), so
         // it needs no barrier before it; its own block-wide OR is the barrier that publishes the new positions to everybody.
-        if (need || NM_DBG(4)) __syncthreads();
+        if (have_need && !need) need = pre_need;
+        else if (need || NM_DBG(4)) __syncthreads();
         else {
-            // the list built at (x0, L0) still covers every pair within rc of the affinely rescaled reference if
-            // max_i |x_i - (L/L0) x0_i| <= ((L/L0)(rc+skin) - rc)/2
-            const double sc = L / L0;
-            const double thr = 0.5 * (sc * (p.rc + p.skin) - p.rc), thr2 = thr * thr;
-            int bad = !(thr > 0.0);
-            for (int i = tid; i < N; i += BLOCK) {
-                double dx = px[i] - sc * x0[i], dy = py[i] - sc * y0[i], dz = pz[i] - sc * z0[i];
-                dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
-                if (dx * dx + dy * dy + dz * dz > thr2) bad = 1;
-            }
-            need = block_any<NW, NVMAX>(bad != 0, red, parity);
+            ListCheck c;
+            check_begin(c);
+            for (int i = tid; i < N; i += BLOCK) check_atom(c, i, px[i], py[i], pz[i]);
+            need = block_any<NW, NVMAX>(c.bad != 0, red, parity);
         }
         PROF_END(1);
         TLINE(1);
@@ -598,29 +749,36 @@ struct Replica {
         PROF_BEGIN();
         if (NM_DBG(16)) { }
         else if constexpr (C::POT == 1) { if (want_e) pair_loop_sc<true>(invL, eacc, wacc, nacc); else pair_loop_sc<false>(invL, eacc, wacc, nacc); }
-        else if (want_e) pair_loop<true>(invL, eacc, wacc, nacc);
-        else pair_loop<false>(invL, eacc, wacc, nacc);
+        else if (want_e) pair_loop<true>(invL, eacc, wacc, nacc, false, 0.0, 0.0);
+        else pair_loop<false>(invL, eacc, wacc, nacc, fuse, dtfm, h);
         PROF_END(3);
         TLINE(3);
         PROF_BEGIN();
         st_evals += 1.0;
         double s[3] = { eacc, wacc, nacc };
         if (want_e) block_sum<3, NW, NVMAX>(s, red, parity); // over this workgroup's atoms
+        else __syncthreads();                                 // nobody reads positions any more: they may be advanced
         PROF_END(4);
-        PROF_BEGIN();
-        if (Q > 1 && !NM_DBG(8)) cluster_exchange(want_e, s);
-        else if (!want_e || Q > 1) __syncthreads();
-        PROF_END(14);
         TLINE(4);
-        PROF_BEGIN();
-        if (want_e) {
-            U = 0.5 * s[0]; W = 0.5 * s[1];
-            st_eevals += 1.0; st_pairs += 0.5 * s[2];
-            if (!(U == U) || isinf(U)) status |= ST_NONFINITE;
-        }
-        PROF_END(4);
+        if (want_e) { psum[0] = s[0]; psum[1] = s[1]; psum[2] = s[2]; }
         ++tl_n;
         fresh = true;
+    }
+
+    __device__ void take_sums()
+    {
+        U = 0.5 * psum[0]; W = 0.5 * psum[1];
+        st_eevals += 1.0; st_pairs += 0.5 * psum[2];
+        if (!(U == U) || isinf(U)) status |= ST_NONFINITE;
+    }
+    // completes an energy evaluation; `extra` is one more per-workgroup partial sum that rides along
+    __device__ double finish_sums(double extra)
+    {
+        double s[4] = { psum[0], psum[1], psum[2], extra };
+        exchange_sums<4>(s);
+        psum[0] = s[0]; psum[1] = s[1]; psum[2] = s[2];
+        take_sums();
+        return s[3];
     }
 
     // ------------------------------------------------------------------ velocity commands (remcmc:604-606)
@@ -797,7 +955,7 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
         if (i < a1) {
             const double xi = px[i], yi = py[i], zi = pz[i];
             const int c = cnt[i];
-            const unsigned long long *nb64 = (const unsigned long long *)nbr;
+            const unsigned long long *nb64 = (const unsigned long long *)nbr.ptr();
             const int mine = (c - sub + TPA - 1) / TPA;
             for (int k = 0; k < mine; ++k) {
                 const unsigned long long wd = nb64[((size_t)(k >> 3) * NMAX + i) * TPA + sub];
@@ -813,21 +971,25 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
         for (int off = TPA / 2; off >= 1; off >>= 1) r += __shfl_xor(r, off, 64);
         if (i < a1 && sub == 0) {
             rho[i] = r;
-            if (Q > 1) put_granule(xg + 2 * (C::XG_RHO + i), r, mg);
+            if (Q > 1) put_granule(xg + 2 * (C::XG_RHO + i), r, my_magic());
         }
     }
-    int timeout = 0;
-    if (Q > 1) { // densities of the atoms the other workgroups own
+    int timeout = 0, poisoned = 0;
+    if (Q > 1) { // densities of the atoms the other workgroups own (an exchange of its own generation)
         const int nother = N - (a1 - a0);
         for (int o = tid; o < nother; o += BLOCK) {
             const int i = o < a0 ? o : o + (a1 - a0);
             double *const g1[1] = { xg + 2 * (C::XG_RHO + i) };
             double v1[1];
-            int dummy = 0;
-            if (get_granules<1>(g1, mg, v1, timeout, dummy)) rho[i] = v1[0];
+            if (get_granules<1>(g1, mg, v1, timeout, poisoned)) rho[i] = v1[0];
         }
+        ++gen;
     }
-    if (block_any<NW, NVMAX>(timeout != 0, red, parity)) { status |= ST_SYNC_TIMEOUT; return; }
+    {
+        const int fl = block_any2<NW, NVMAX>(timeout != 0, poisoned != 0, red, parity);
+        if (fl & 2) status |= ST_LIST_OVERFLOW; // a peer's list overflowed: finish this evaluation with the others, then leave
+        if (fl & 1) { status |= ST_SYNC_TIMEOUT; return; }
+    }
     double sq_own = 0.0; // sum over own atoms of sqrt(rho_i), by the atom's elementwise owner
     for (int i = tid; i < N; i += BLOCK) {
         const double sr = sqrt(rho[i]);
@@ -842,7 +1004,7 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
         if (i < a1) {
             const double xi = px[i], yi = py[i], zi = pz[i], isi = rho[i];
             const int c = cnt[i];
-            const unsigned long long *nb64 = (const unsigned long long *)nbr;
+            const unsigned long long *nb64 = (const unsigned long long *)nbr.ptr();
             const int mine = (c - sub + TPA - 1) / TPA;
             for (int k = 0; k < mine; ++k) {
                 const unsigned long long wd = nb64[((size_t)(k >> 3) * NMAX + i) * TPA + sub];
@@ -866,15 +1028,7 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
             ax += __shfl_xor(ax, off, 64); ay += __shfl_xor(ay, off, 64); az += __shfl_xor(az, off, 64);
             if (WANT_E) { e += __shfl_xor(e, off, 64); w += __shfl_xor(w, off, 64); np += __shfl_xor(np, off, 64); }
         }
-        if (i < a1 && sub == 0) {
-            fx[i] = ax; fy[i] = ay; fz[i] = az; eacc += e; wacc += w; nacc += np;
-            if (Q > 1) {
-                const unsigned long long mgf = mg ^ ((status & ST_LIST_OVERFLOW) ? POISON : 0ull);
-                put_granule(xg + 2 * (size_t)i, ax, mgf);
-                put_granule(xg + 2 * (size_t)(NMAX + i), ay, mgf);
-                put_granule(xg + 2 * (size_t)(2 * NMAX + i), az, mgf);
-            }
-        }
+        if (i < a1 && sub == 0) { fx[i] = ax; fy[i] = ay; fz[i] = az; eacc += e; wacc += w; nacc += np; }
     }
     // the caller halves the summed energy (pair terms are counted twice in a full list): fold the embedding term in as -2 eps c sqrt(rho)
     eacc -= 2.0 * eps * cc * sq_own;
@@ -889,7 +1043,6 @@ enum : int { PH_INIT = 0, PH_BULK = 1, PH_VMC = 2, PH_HMC_START = 3, PH_HMC_STEP
 template <class C>
 __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
     constexpr int BLOCK = C::BLOCK;
     // cluster mapping: with 8 | nslots the Q members of a cluster share blockIdx % 8, i.e. one XCD (and its L2) under the
     // observed round-robin placement — a speed matter only, the hand-off protocol does not depend on it
@@ -899,7 +1052,7 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
     else { slot = b / Q; qq = b % Q; }
     const int buf = p.slot2buf[slot];
     const int tid = threadIdx.x;
-    Replica<C> R(p, smem, slot, qq);
+    Replica<C> R(p, slot, qq);
     const bool writer = (tid == 0 && qq == 0); // one workgroup of the cluster writes the replica's results
     const int N = p.N;
 
@@ -920,12 +1073,35 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
     // state carried across the evaluation of a move
     int phase = PH_INIT, m = 0, hstep = 0;
     bool want_e = true, skip_eval = false;
+    double mv2new = 0.0; // kinetic-energy sum delivered with the last evaluation of a trajectory
+    bool have_need = false, pre_need = false; // rebuild decision delivered with a position hand-over (HMC steps)
     double U0 = 0.0, W0 = 0.0, c_pe = 0.0, c_vol = 0.0, c_volnew = 0.0, c_boxl = 0.0, c_h = 0.0, c_dtfm = 0.0;
 
     for (;;) {
-        if (!skip_eval) R.eval(want_e);
+        const int st_before = R.status;
+        // a force-only evaluation inside a trajectory integrates and publishes in its pair loop (lj/cut kernels)
+        const bool fuse = (C::POT == 0) && phase == PH_HMC_STEP && !want_e && !skip_eval;
+        if (!skip_eval) {
+            R.eval(want_e, have_need, pre_need, fuse, c_dtfm, c_h);
+            // cluster-wide U, W of an energy evaluation — ONE exchange site.  The evaluation before the last half kick of a
+            // trajectory (the only energy evaluation in phase PH_HMC_STEP) takes the kinetic energy along in the same exchange.
+            if (want_e && !(st_before & fatal) && !(R.status & (ST_BOX_TOO_SMALL | ST_SYNC_TIMEOUT))) {
+                double extra = 0.0;
+                if (phase == PH_HMC_STEP) {
+                    for (int i = R.a0 + tid; i < R.a1; i += BLOCK) { // final_integrate of the last step
+                        R.vx[i] += c_dtfm * R.fx[i]; R.vy[i] += c_dtfm * R.fy[i]; R.vz[i] += c_dtfm * R.fz[i];
+                    }
+                    extra = R.own_mv2();
+                }
+                mv2new = R.finish_sums(extra);
+            }
+        }
         skip_eval = false;
-        if (R.status & fatal) break;
+        have_need = false;
+        if (R.status & fatal) {
+            if (R.Q > 1 && (R.status & ST_LIST_OVERFLOW)) R.publish_poison();
+            break;
+        }
 #ifdef NM_PROF
         unsigned long long &prof_t0 = R.prof_t0; unsigned long long (&prof_acc)[NM_PROF_SLOTS] = R.prof_acc;
         const int prof_phase = phase;
@@ -934,6 +1110,7 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
 
         // ---------------- part of the move after its evaluation
         bool move_done = false, acc = false;
+        int share = 0; // 1: half kick + drift, 2: two half kicks + drift, then the position hand-over
         double crit = 0.0, branch = 0.0;
         if (phase == PH_INIT) {
             if (p.eval_only) { // nm_eval: batched lj_energy_force on the resident states
@@ -942,8 +1119,8 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
                     double *st = p.stats + 4 * (size_t)slot;
                     st[0] += R.st_evals; st[1] += R.st_rebuilds; st[2] += R.st_eevals; st[3] += R.st_pairs;
                 }
-                if (p.evalF && qq == 0)
-                    for (int a = tid; a < 3 * N; a += BLOCK) {
+                if (p.evalF) // every workgroup holds the forces of its own atoms
+                    for (int a = 3 * R.a0 + tid; a < 3 * R.a1; a += BLOCK) {
                         const int i = a / 3, c = a - 3 * i;
                         p.evalF[(size_t)slot * 3 * N + a] = (c == 0 ? R.fx : c == 1 ? R.fy : R.fz)[i];
                     }
@@ -968,39 +1145,30 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
             U0 = R.U; W0 = R.W;
             c_pe = R.U / et + 0.5 * p.mvv2e * R.sum_mv2() / et; // etot
             hstep = 0;
-            for (int i = tid; i < N; i += BLOCK) { // fix nve initial_integrate
-                R.vx[i] += c_dtfm * R.fx[i]; R.vy[i] += c_dtfm * R.fy[i]; R.vz[i] += c_dtfm * R.fz[i];
-                R.px[i] += c_h * R.vx[i]; R.py[i] += c_h * R.vy[i]; R.pz[i] += c_h * R.vz[i];
-            }
+            share = 1;
             phase = PH_HMC_STEP; want_e = (p.nstps == 1);
-            PROF_END(5 + PH_HMC_START);
-            continue;
         } else { // PH_HMC_STEP: forces at the new positions are in
             ++hstep;
             if (hstep < p.nstps) {
-                for (int i = tid; i < N; i += BLOCK) { // final_integrate of this step + initial_integrate of the next, same arithmetic
-                    const double gx = R.fx[i], gy = R.fy[i], gz = R.fz[i];
-                    double ux = __builtin_fma(c_dtfm, gx, R.vx[i]), uy = __builtin_fma(c_dtfm, gy, R.vy[i]), uz = __builtin_fma(c_dtfm, gz, R.vz[i]);
-                    ux = __builtin_fma(c_dtfm, gx, ux); uy = __builtin_fma(c_dtfm, gy, uy); uz = __builtin_fma(c_dtfm, gz, uz);
-                    R.vx[i] = ux; R.vy[i] = uy; R.vz[i] = uz;
-                    R.px[i] += c_h * ux; R.py[i] += c_h * uy; R.pz[i] += c_h * uz;
-                }
+                share = fuse ? 3 : 2; // final_integrate of this step + initial_integrate of the next
                 want_e = (hstep == p.nstps - 1);
-                PROF_END(5 + PH_HMC_STEP);
-                continue;
+            } else {
+                const double etotnew = R.U / et + 0.5 * p.mvv2e * mv2new / et; // remcmc:618-622
+                crit = etotnew - c_pe;
+                if (p.md_mode) acc = true; // plain NVE run (init_sample -is, remcmc:421-425): nothing to accept
+                else {
+                    acc = R.metropolis(crit, S_ACC, (uint32_t)m, 0);
+                    if (acc) nah += 1.0;
+                    else { R.restore(true); R.wrap(); R.U = U0; R.W = W0; }
+                }
+                branch = 2.0; move_done = true;
             }
-            for (int i = tid; i < N; i += BLOCK) { // final_integrate of the last step
-                R.vx[i] += c_dtfm * R.fx[i]; R.vy[i] += c_dtfm * R.fy[i]; R.vz[i] += c_dtfm * R.fz[i];
-            }
-            const double etotnew = R.U / et + 0.5 * p.mvv2e * R.sum_mv2() / et; // remcmc:618-622
-            crit = etotnew - c_pe;
-            if (p.md_mode) acc = true; // plain NVE run (init_sample -is, remcmc:421-425): nothing to accept
-            else {
-                acc = R.metropolis(crit, S_ACC, (uint32_t)m, 0);
-                if (acc) nah += 1.0;
-                else { R.restore(true); R.wrap(); R.U = U0; R.W = W0; }
-            }
-            branch = 2.0; move_done = true;
+        }
+        if (share) { // ONE hand-over site
+            pre_need = R.advance_and_share(share, c_dtfm, c_h);
+            have_need = true;
+            PROF_END(5 + prof_phase);
+            continue;
         }
         if (move_done) {
             if (p.trace && writer) {
@@ -1080,8 +1248,13 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
     }
 #endif
     // lammps_extract (remcmc:377-391) and the acceptance ratios (remcmc:685-688)
-    const double smv2 = R.sum_mv2();
-    if (qq == 0) R.store(buf);
+    double smv2;
+    {
+        double k4[4] = { R.own_mv2(), 0.0, 0.0, 0.0 };
+        if (!(R.status & fatal)) R.template exchange_sums<4>(k4); // (a cluster that is leaving on an error is no longer in step)
+        smv2 = k4[0];
+    }
+    R.store(buf);
     if (writer) {
         const double dof = 3.0 * N - 3.0;
         const double temp = smv2 * p.mvv2e / (dof * p.kB);
