@@ -142,6 +142,10 @@ struct Replica {
     int parity = 0;
     // block-uniform scalars
     double L = 0.0, L0 = 0.0, U = 0.0, W = 0.0;
+    // derived from (L, L0), refreshed by box_consts() only when one of them changed (three fp64 divisions otherwise sit on the
+    // critical path between two pair loops of an HMC trajectory): 1/L, L/L0 and the squared list-validity bound
+    double bc_L = -1.0, bc_L0 = -1.0, bc_invL = 0.0, bc_sc = 0.0, bc_thr2 = 0.0;
+    bool bc_bad = true;
     double psum[3] = { 0.0, 0.0, 0.0 }; // partial (then cluster-wide) sums of the last energy evaluation: 2U, 2W, 2 pairs
     bool list_ok = false, fresh = false;
     int status = 0;
@@ -546,7 +550,7 @@ struct Replica {
     template <int K>
     __device__ __forceinline__ bool get_granules(double *const (&g)[K], unsigned long long mg, double (&out)[K], int &timeout, int &poisoned)
     {
-        const unsigned long long t0 = wall_clock64(); // 100 MHz
+        unsigned long long t0 = 0; // 100 MHz clock, read only once polls have failed
         int spins = 0;
         for (;;) {
             u64x2 w[K];
@@ -575,7 +579,11 @@ struct Replica {
                 poisoned |= po;
                 return true;
             }
-            if ((++spins & 63) == 0 && wall_clock64() - t0 > 200000000ull) { timeout = 1; return false; } // 2 s
+            if ((++spins & 63) == 0) {
+                const unsigned long long now = wall_clock64();
+                if (t0 == 0) t0 = now | 1ull;
+                else if (now - t0 > 200000000ull) { timeout = 1; return false; } // 2 s
+            }
         }
     }
 
@@ -644,15 +652,22 @@ struct Replica {
 
     // the list-validity test of one atom at (x, y, z)
     struct ListCheck { double sc, thr2, invL; int bad; };
-    __device__ __forceinline__ void check_begin(ListCheck &c) const
+    __device__ __forceinline__ void box_consts()
     {
+        if (L == bc_L && L0 == bc_L0) return;
+        bc_L = L; bc_L0 = L0;
+        bc_invL = 1.0 / L;
         // the list built at (x0, L0) still covers every pair within rc of the affinely rescaled reference if
         // max_i |x_i - (L/L0) x0_i| <= ((L/L0)(rc+skin) - rc)/2
-        c.sc = L / L0;
-        const double thr = 0.5 * (c.sc * (p.rc + p.skin) - p.rc);
-        c.thr2 = thr * thr;
-        c.invL = 1.0 / L;
-        c.bad = !(thr > 0.0);
+        bc_sc = L / L0;
+        const double thr = 0.5 * (bc_sc * (p.rc + p.skin) - p.rc);
+        bc_thr2 = thr * thr;
+        bc_bad = !(thr > 0.0);
+    }
+    __device__ __forceinline__ void check_begin(ListCheck &c)
+    {
+        box_consts();
+        c.sc = bc_sc; c.thr2 = bc_thr2; c.invL = bc_invL; c.bad = bc_bad ? 1 : 0;
     }
     __device__ __forceinline__ void check_atom(ListCheck &c, int i, double x, double y, double z) const
     {
@@ -725,7 +740,6 @@ struct Replica {
         if (status & (ST_SYNC_TIMEOUT | ST_LIST_OVERFLOW)) return; // learnt from the last hand-over: the cluster is leaving
         if (!(L >= 2.0 * p.rc)) { status |= ST_BOX_TOO_SMALL; __syncthreads(); return; } // minimum-image limit
         bool need = !list_ok;
-        const double invL = 1.0 / L;
         TLINE(0);
         PROF_BEGIN();
         // The validity check reads only a thread's own atoms (written by itself) and x0 (settled since the last rebuild), so
@@ -744,6 +758,8 @@ struct Replica {
         if (need) rebuild();
         PROF_END(2);
         TLINE(2);
+        box_consts();
+        const double invL = bc_invL;
 
         double eacc = 0.0, wacc = 0.0, nacc = 0.0;
         PROF_BEGIN();
