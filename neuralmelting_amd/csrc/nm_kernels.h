@@ -518,7 +518,7 @@ struct Replica {
     // Two passes over the same full list: densities of the own atoms, (cluster: exchange them,) then forces with
     // fp = eps [ 7 (a/r)^7 - 6 (c/2)(1/sqrt(rho_i) + 1/sqrt(rho_j)) (a/r)^6 ] / r^2.
     template <bool WANT_E>
-    __device__ __forceinline__ void pair_loop_sc(double invL, double &eacc, double &wacc, double &nacc);
+    __device__ __forceinline__ void pair_loop_sc(double invL, double &eacc, double &wacc, double &nacc, bool fuse, double dtfm, double h);
 
     // ------------------------------------------------------------------ cluster hand-off (Q workgroups per replica)
     // Data-tagged granules (MI355X guide, hand-off price list "handoff-1to1"): every exchanged double travels as ONE
@@ -764,7 +764,7 @@ struct Replica {
         double eacc = 0.0, wacc = 0.0, nacc = 0.0;
         PROF_BEGIN();
         if (NM_DBG(16)) { }
-        else if constexpr (C::POT == 1) { if (want_e) pair_loop_sc<true>(invL, eacc, wacc, nacc); else pair_loop_sc<false>(invL, eacc, wacc, nacc); }
+        else if constexpr (C::POT == 1) { if (want_e) pair_loop_sc<true>(invL, eacc, wacc, nacc, false, 0.0, 0.0); else pair_loop_sc<false>(invL, eacc, wacc, nacc, fuse, dtfm, h); }
         else if (want_e) pair_loop<true>(invL, eacc, wacc, nacc, false, 0.0, 0.0);
         else pair_loop<false>(invL, eacc, wacc, nacc, fuse, dtfm, h);
         PROF_END(3);
@@ -958,7 +958,7 @@ struct Replica {
 
 template <class C>
 template <bool WANT_E>
-__device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &eacc, double &wacc, double &nacc)
+__device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &eacc, double &wacc, double &nacc, bool fuse, double dtfm, double h)
 {
     const int g = tid / TPA, sub = tid - g * TPA;
     const double rc2 = p.rc * p.rc, a2 = p.sc_a2, eps = p.sc_eps, cc = p.sc_c;
@@ -1044,7 +1044,23 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
             ax += __shfl_xor(ax, off, 64); ay += __shfl_xor(ay, off, 64); az += __shfl_xor(az, off, 64);
             if (WANT_E) { e += __shfl_xor(e, off, 64); w += __shfl_xor(w, off, 64); np += __shfl_xor(np, off, 64); }
         }
-        if (i < a1 && sub == 0) { fx[i] = ax; fy[i] = ay; fz[i] = az; eacc += e; wacc += w; nacc += np; }
+        if (i < a1 && sub == 0) {
+            eacc += e; wacc += w; nacc += np;
+            if (!WANT_E && fuse) { // integrate and publish on the spot, as pair_loop does (the densities' exchange took generation gen-1)
+                double ux = __builtin_fma(dtfm, ax, vx[i]), uy = __builtin_fma(dtfm, ay, vy[i]), uz = __builtin_fma(dtfm, az, vz[i]);
+                ux = __builtin_fma(dtfm, ax, ux); uy = __builtin_fma(dtfm, ay, uy); uz = __builtin_fma(dtfm, az, uz);
+                vx[i] = ux; vy[i] = uy; vz[i] = uz;
+                ax = __builtin_fma(h, ux, px[i]); ay = __builtin_fma(h, uy, py[i]); az = __builtin_fma(h, uz, pz[i]);
+                if (Q > 1) {
+                    double *xp = xb + (size_t)(gen & 1) * C::XBUF_DOUBLES;
+                    const unsigned long long mgp = my_magic();
+                    put_granule(xp + 2 * (size_t)i, ax, mgp);
+                    put_granule(xp + 2 * (size_t)(NMAX + i), ay, mgp);
+                    put_granule(xp + 2 * (size_t)(2 * NMAX + i), az, mgp);
+                }
+            }
+            fx[i] = ax; fy[i] = ay; fz[i] = az;
+        }
     }
     // the caller halves the summed energy (pair terms are counted twice in a full list): fold the embedding term in as -2 eps c sqrt(rho)
     eacc -= 2.0 * eps * cc * sq_own;
@@ -1095,8 +1111,8 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
 
     for (;;) {
         const int st_before = R.status;
-        // a force-only evaluation inside a trajectory integrates and publishes in its pair loop (lj/cut kernels)
-        const bool fuse = (C::POT == 0) && phase == PH_HMC_STEP && !want_e && !skip_eval;
+        // a force-only evaluation inside a trajectory integrates and publishes in its pair loop
+        const bool fuse = phase == PH_HMC_STEP && !want_e && !skip_eval;
         if (!skip_eval) {
             R.eval(want_e, have_need, pre_need, fuse, c_dtfm, c_h);
             // cluster-wide U, W of an energy evaluation — ONE exchange site.  The evaluation before the last half kick of a
