@@ -478,16 +478,39 @@ struct Replica {
                         }
                     }
                 } else {
-                    static_assert(sizeof(IdxT) == 2 || C::CH == 1, "chunked lists hold 16-bit indices");
+                    static_assert(sizeof(IdxT) == 2 && C::CH == 4, "lists outside LDS: chunks of four 16-bit indices");
+                    // The list lives in HBM/L2: one 8-byte load = four neighbours, ~1 us away.  The loads of the NEXT four
+                    // chunks are issued before the arithmetic on the current four, so the latency is paid once per 16 neighbours
+                    // and hidden behind ~16 pair evaluations (issued one chunk at a time it dominated the 6^3 / 8^3 kernels).
+                    constexpr int PF = 4, W = 2;
                     const unsigned long long *nb64 = (const unsigned long long *)nbr.ptr();
-                    for (int c0 = sub; c0 * C::CH < c; c0 += TPA) { // one 8-byte load = four neighbours
-                        const unsigned long long wd = nb64[(size_t)c0 * NMAX + i];
+                    const int nch = (c + C::CH - 1) / C::CH;              // chunks of atom i
+                    const int mych = (nch - sub + TPA - 1) / TPA;         // chunks sub, sub+TPA, ... belong to this thread
+                    unsigned long long cur[PF], nxt[PF];
 #pragma unroll
-                        for (int q = 0; q < C::CH; ++q) {
-                            const bool ok = (c0 * C::CH + q) < c;
-                            const int j = ok ? (int)((wd >> (16 * q)) & 0xFFFFull) : i; // tail entries of the last chunk are garbage
-                            pair_one<WANT_E>(j, xi, yi, zi, invL, rc2, ok, ax, ay, az, e, w, np);
+                    for (int q = 0; q < PF; ++q) cur[q] = q < mych ? nb64[(size_t)(sub + q * TPA) * NMAX + i] : 0ull;
+                    for (int k0 = 0; k0 < mych; k0 += PF) {
+#pragma unroll
+                        for (int q = 0; q < PF; ++q) nxt[q] = (k0 + PF + q) < mych ? nb64[(size_t)(sub + (k0 + PF + q) * TPA) * NMAX + i] : 0ull;
+#pragma unroll
+                        for (int q = 0; q < PF; ++q) {
+                            if (k0 + q < mych) {
+                                const int first = (sub + (k0 + q) * TPA) * C::CH; // list slot of this chunk's first entry
+#pragma unroll
+                                for (int e0 = 0; e0 < C::CH; e0 += W) {
+                                    int jj[W];
+                                    bool ok[W];
+#pragma unroll
+                                    for (int r = 0; r < W; ++r) {
+                                        ok[r] = (first + e0 + r) < c; // tail entries of the last chunk are garbage
+                                        jj[r] = ok[r] ? (int)((cur[q] >> (16 * (e0 + r))) & 0xFFFFull) : i;
+                                    }
+                                    pair_vec<WANT_E, W>(jj, ok, xi, yi, zi, invL, rc2, ax, ay, az, e, w, np);
+                                }
+                            }
                         }
+#pragma unroll
+                        for (int q = 0; q < PF; ++q) cur[q] = nxt[q];
                     }
                 }
             }
