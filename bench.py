@@ -34,7 +34,7 @@ def main():
     ap.add_argument('--mod', type=int, default=128, help='moves per block (-sm)')
     ap.add_argument('--el', type=str, default='LJ', help="element (-e): LJ, or Al = BASELINE config 4 (Sutton-Chen EAM, metal units)")
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
-    ap.add_argument('--cpu-cycles', type=int, default=2)
+    ap.add_argument('--cpu-cycles', type=int, default=4)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -155,7 +155,7 @@ def main():
 def measured_traffic(natoms, ns, mod):
     """HBM bytes per launch of nm_block_kernel from the committed rocprofv3 PMC passes (profiles/), for the workload
     they were taken on; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  None for other workloads."""
-    f = os.path.join(ROOT, 'profiles', 'r01_pmc_block_kernel_cluster4.json')
+    f = os.path.join(ROOT, 'profiles', 'r01_pmc_block_kernel_final.json')
     if not (os.path.isfile(f) and natoms == 256 and ns == 64 and mod == 128):
         return None
     d = json.load(open(f))

@@ -374,27 +374,6 @@ struct Replica {
         return __builtin_fma(y, e, y);
     }
 
-    // One listed neighbour: branch-free (a wave almost always has lanes inside the cutoff, so predication costs
-    // nothing and lets two neighbours' instruction streams interleave).
-    template <bool WANT_E>
-    __device__ __forceinline__ void pair_one(int j, double xi, double yi, double zi, double invL, double rc2, bool valid,
-                                             double &ax, double &ay, double &az, double &e, double &w, double &np)
-    {
-        double dx = xi - px[j], dy = yi - py[j], dz = zi - pz[j];
-        dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
-        const double r2 = dx * dx + dy * dy + dz * dz;
-        const bool in = valid && (r2 < rc2);
-        const double r2i = recip(r2);
-        const double r6i = r2i * r2i * r2i;
-        const double fp = in ? r6i * (48.0 * r6i - 24.0) * r2i : 0.0;
-        ax += dx * fp; ay += dy * fp; az += dz * fp;
-        if (WANT_E) {
-            e += in ? r6i * (4.0 * r6i - 4.0) : 0.0;
-            w += r2 * fp;
-            np += in ? 1.0 : 0.0;
-        }
-    }
-
     // W listed neighbours at once, written stage by stage so that W independent dependency chains interleave (fp64 results
     // are not available to the next instruction of the same chain for several cycles).
     template <bool WANT_E, int W>
