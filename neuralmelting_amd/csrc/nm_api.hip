@@ -119,6 +119,11 @@ void fill_params(const nm_ctx *c, KParams &p)
     p.dbg = 0;
     p.tline = c->d_tline;
     if (const char *e = std::getenv("NM_DBG")) p.dbg = std::atoi(e);
+    p.inj_rebuild = -1; p.inj_q = 0;
+    if (const char *e = std::getenv("NM_INJECT_OVERFLOW")) { // tests of the error path only
+        int n = -1, q = 0;
+        if (std::sscanf(e, "%d,%d", &n, &q) >= 1) { p.inj_rebuild = n; p.inj_q = q; }
+    }
 }
 
 template <class C>

@@ -45,6 +45,8 @@ struct KParams {
     unsigned long long *prof;      // diagnostic build only
     int cus;                       // workgroups (CUs) cooperating on one replica
     int dbg;                       // NM_DBG: timing experiments only (skips work, results are wrong)
+    int inj_rebuild, inj_q;        // fault injection for the tests of the error path (NM_INJECT_OVERFLOW=n,q): the n-th list rebuild of
+                                   // a block reports an overflow in workgroup q of every cluster; -1 = off
     unsigned long long *tline;     // experiment build only: 100 MHz timestamps of slot 0's evaluations [q][wave][eval][8]
     double *xbuf;                  // [slot][2][XBUF_DOUBLES]: force slices + partial sums exchanged inside a cluster
     uint32_t launch_id;            // distinguishes the granules of successive launches

@@ -339,6 +339,7 @@ struct Replica {
         for (int i = tid; i < N; i += BLOCK) { x0[i] = px[i]; y0[i] = py[i]; z0[i] = pz[i]; }
         L0 = L;
         list_ok = true;
+        if (p.inj_rebuild >= 0 && (int)st_rebuilds == p.inj_rebuild && q == p.inj_q % Q) ovf = 1; // fault injection (tests)
         st_rebuilds += 1.0;
         if (block_any<NW, NVMAX>(ovf != 0, red, parity)) status |= ST_LIST_OVERFLOW;
     }

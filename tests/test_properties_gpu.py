@@ -90,3 +90,73 @@ def test_cluster_matches_single_workgroup(oracle, monkeypatch):
     np.testing.assert_array_equal(p4, p1)
     np.testing.assert_allclose(s4[0], s1[0], rtol=0, atol=1e-9)
     np.testing.assert_array_equal(s4[3], s1[3])
+
+
+def _dense_engine(np_rows, nt, box_edge, seed=3):
+    """replicas of 256 atoms placed at random in a box so small that some atoms have more neighbours than list slots"""
+    import neuralmelting_amd as nm
+    P, T = grids(np_rows, nt)
+    rng = np.random.default_rng(seed)
+    ns = np_rows * nt
+    x = rng.random((ns, 768)) * box_edge
+    e = nm.Engine(256, P, T)
+    e.set_state(x, np.zeros((ns, 768)), np.full(ns, box_edge), np.tile([0.03125, 0.03125, 0.00390625], (ns, 1)))
+    return nm, e
+
+
+@pytest.mark.parametrize('np_rows,nt', [(8, 8), (16, 8), (32, 8)])        # 4, 2 and 1 workgroups per replica (192 list slots)
+def test_list_overflow_is_reported_by_the_whole_cluster_without_timeouts(np_rows, nt):
+    """error path of the cluster hand-over: the workgroup whose list overflows poisons what it publishes, its peers take the
+    status over and the replica leaves the block at once — NM_ERR_STATE with the reason, not a 2 s hand-over timeout"""
+    import time
+    nm, e = _dense_engine(np_rows, nt, 5.2)      # density 1.82: ~170 listed neighbours on average, tails beyond the 192 / 256 slots
+    t0 = time.perf_counter()
+    with pytest.raises(nm.NMError) as err:
+        e.eval()
+    assert err.value.code == -3 and 'neighbour list overflow' in str(err.value) and 'timed out' not in str(err.value)
+    e.set_step(0)
+    e.run_block(8)
+    with pytest.raises(nm.NMError) as err:
+        e.synchronize()
+    dt = time.perf_counter() - t0
+    assert err.value.code == -3 and 'neighbour list overflow' in str(err.value) and 'timed out' not in str(err.value)
+    assert dt < 1.5, dt
+    e.close()
+
+
+def test_box_smaller_than_twice_the_cutoff_is_refused():
+    nm, e = _dense_engine(8, 8, 4.9)
+    with pytest.raises(nm.NMError) as err:
+        e.eval()
+    assert err.value.code == -3 and 'box edge < 2*rc' in str(err.value)
+    e.close()
+
+
+@pytest.mark.parametrize('el,nth,q', [('LJ', n, q) for n in range(0, 12) for q in (0, 2)] + [('Al', n, 1) for n in (0, 1, 2, 5, 9)])
+def test_list_overflow_anywhere_in_a_block_stops_the_whole_cluster(monkeypatch, el, nth, q):
+    """Physical states of these systems do not overflow a list, so the error path is driven by fault injection
+    (NM_INJECT_OVERFLOW=n,q: the n-th rebuild of a block "overflows" in workgroup q of every cluster).  Depending on n the
+    rebuild falls into the first evaluation, a PMC/VMC energy evaluation or a force-only evaluation in the middle of an HMC
+    trajectory, where that workgroup has nothing to publish but poison (publish_poison) — or, for the EAM, between its two
+    passes.  In every case all workgroups of the cluster must stop at once: NM_ERR_STATE with the reason, no 2 s hand-over
+    timeout, no hang."""
+    import time
+    import neuralmelting_amd as nm
+    from neuralmelting_amd import lattice
+    monkeypatch.setenv('NM_INJECT_OVERFLOW', '%d,%d' % (nth, q))
+    P = np.linspace(1.0, 8.0, 8, dtype=np.float32)
+    T = np.linspace(0.25, 2.5, 8, dtype=np.float32) if el == 'LJ' else np.linspace(256.0, 2560.0, 8, dtype=np.float32)
+    x, v, box, d = lattice.init_states(4, P, T, 0.03125, 0.03125, el=el)
+    e = nm.Engine(256, P, T, element=el)
+    assert e.cus_per_replica == 4
+    e.set_state(x, v, box, d)
+    t0 = time.perf_counter()
+    e.set_step(0)
+    e.run_block(24)
+    with pytest.raises(nm.NMError) as err:
+        e.synchronize()
+    dt = time.perf_counter() - t0
+    assert err.value.code == -3 and 'neighbour list overflow' in str(err.value) and 'timed out' not in str(err.value)
+    assert dt < 1.0, dt
+    monkeypatch.delenv('NM_INJECT_OVERFLOW')
+    e.close()
