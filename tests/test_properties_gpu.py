@@ -160,3 +160,47 @@ def test_list_overflow_anywhere_in_a_block_stops_the_whole_cluster(monkeypatch, 
     assert dt < 1.0, dt
     monkeypatch.delenv('NM_INJECT_OVERFLOW')
     e.close()
+
+
+def test_long_run_statistics_agree_with_the_oracle(oracle):
+    """Beyond the horizon where the two chains are still identical move by move (rounding differences are amplified by the
+    dynamics after a few cycles) they must remain two samples of the SAME ensemble: 8x8 grid, 28 cycles of 64 moves with
+    adaptation and replica exchange on both sides, same seeds; per-slot means of U and V over the last 20 cycles compared in
+    units of their own standard error, acceptance ratios and adapted step sizes compared directly."""
+    import neuralmelting_amd as nm
+    P, T = grids(8, 8)
+    cycles, mod, burn = 28, 64, 8
+    lp = OracleLoop(oracle, 4, P, T)
+    e = nm.Engine(256, P, T)
+    e.set_state(lp.x, lp.v, lp.box, lp.d)
+    g_rows, o_rows, same = [], [], 0
+    for step in range(cycles):
+        e.set_step(step)
+        e.run_block(mod)
+        lp.run_block(mod, step)
+        g, o = e.thermo(), lp.rows()
+        if np.array_equal(g[:, 8:14], o[:, 8:14]) and same == step:
+            same += 1                                       # cycles in which every counter of every replica still agrees
+        g_rows.append(g)
+        o_rows.append(o)
+        e.adapt()
+        lp.adapt()
+        e.exchange(count=False)
+        lp.exchange(step)
+    e.close()
+    g, o = np.array(g_rows)[burn:], np.array(o_rows)[burn:]
+    assert same >= 2
+    n = g.shape[0]
+    for col, name in ((1, 'pe'), (4, 'vol')):
+        # slot statistics mix the replicas that visit the slot: compare slot means against the pooled scatter
+        dm = g[:, :, col].mean(0) - o[:, :, col].mean(0)
+        se = np.sqrt((g[:, :, col].var(0, ddof=1) + o[:, :, col].var(0, ddof=1)) / n)
+        z = np.abs(dm) / np.maximum(se, 1e-12)
+        assert np.median(z) < 2.0 and (z < 8.0).all(), (name, np.sort(z)[-4:])
+        assert abs(dm.mean()) < 4.0 * np.sqrt((se ** 2).mean() / 64) + 1e-9, (name, dm.mean())
+    # acceptance ratios (columns 14-16) averaged over the run and the adapted step sizes (5-7) at its end
+    assert np.abs(g[:, :, 14:17].mean(0) - o[:, :, 14:17].mean(0)).max() < 0.2
+    assert np.abs(g[:, :, 14:17].mean((0, 1)) - o[:, :, 14:17].mean((0, 1))).max() < 0.03
+    ratio = g[-1, :, 5:8] / o[-1, :, 5:8]
+    assert (ratio > 1 / 2.5).all() and (ratio < 2.5).all()
+    assert abs(np.log(ratio).mean()) < 0.15
