@@ -967,27 +967,55 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
     const double rc2 = p.rc * p.rc, a2 = p.sc_a2, eps = p.sc_eps, cc = p.sc_c;
     double *xg = xb ? xb + (size_t)(gen & 1) * C::XBUF_DOUBLES : nullptr;
     const unsigned long long mg = magic();
-    // pass 1: densities of this workgroup's atoms
+    // pass 1: densities of this workgroup's atoms.  Both passes walk the byte list like pair_loop does: one conflict-free 8-byte
+    // read = eight neighbours, two neighbours' dependency chains interleaved stage by stage.
+    constexpr int W = NM_PAIR_W;
+    const unsigned long long *nb64 = (const unsigned long long *)nbr.ptr();
     for (int i0 = a0; i0 < a1; i0 += G) {
         const int i = i0 + g;
         double r = 0.0;
         if (i < a1) {
             const double xi = px[i], yi = py[i], zi = pz[i];
             const int c = cnt[i];
-            const unsigned long long *nb64 = (const unsigned long long *)nbr.ptr();
             const int mine = (c - sub + TPA - 1) / TPA;
-            for (int k = 0; k < mine; ++k) {
-                const unsigned long long wd = nb64[((size_t)(k >> 3) * NMAX + i) * TPA + sub];
-                const int j = (int)((wd >> (8 * (k & 7))) & 0xFFull);
-                double dx = xi - px[j], dy = yi - py[j], dz = zi - pz[j];
-                dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
-                const double r2 = dx * dx + dy * dy + dz * dz;
-                const double q2 = a2 * recip(r2);
-                r += (r2 < rc2) ? q2 * q2 * q2 : 0.0;
+            for (int k0 = 0; k0 < mine; k0 += 8) {
+                const unsigned long long wd = nb64[((size_t)(k0 >> 3) * NMAX + i) * TPA + sub];
+#pragma unroll
+                for (int e0 = 0; e0 < 8; e0 += W) {
+                    if (k0 + e0 < mine) {
+                        double dx[W], dy[W], dz[W], r2[W], y[W], t[W], msk[W];
+#pragma unroll
+                        for (int u = 0; u < W; ++u) {
+                            const bool ok = (k0 + e0 + u) < mine;
+                            const int j = ok ? (int)((wd >> (8 * (e0 + u))) & 0xFFull) : i;
+                            dx[u] = xi - px[j]; dy[u] = yi - py[j]; dz[u] = zi - pz[j];
+                            msk[u] = ok ? 1.0 : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < W; ++u) { dx[u] -= L * rint(dx[u] * invL); dy[u] -= L * rint(dy[u] * invL); dz[u] -= L * rint(dz[u] * invL); }
+#pragma unroll
+                        for (int u = 0; u < W; ++u) {
+                            r2[u] = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
+                            msk[u] = (msk[u] != 0.0 && r2[u] < rc2) ? 1.0 : 0.0;
+                            r2[u] = msk[u] != 0.0 ? r2[u] : 1.0; // a masked lane (itself: r2 = 0) stays finite
+                        }
+#pragma unroll
+                        for (int u = 0; u < W; ++u) y[u] = __builtin_amdgcn_rcp(r2[u]);
+#pragma unroll
+                        for (int u = 0; u < W; ++u) t[u] = __builtin_fma(-r2[u], y[u], 1.0);
+#pragma unroll
+                        for (int u = 0; u < W; ++u) y[u] = __builtin_fma(y[u], t[u], y[u]);
+#pragma unroll
+                        for (int u = 0; u < W; ++u) t[u] = __builtin_fma(-r2[u], y[u], 1.0);
+#pragma unroll
+                        for (int u = 0; u < W; ++u) y[u] = __builtin_fma(y[u], t[u], y[u]) * a2; // (a/r)^2
+#pragma unroll
+                        for (int u = 0; u < W; ++u) r += y[u] * y[u] * y[u] * msk[u];
+                    }
+                }
             }
         }
-#pragma unroll
-        for (int off = TPA / 2; off >= 1; off >>= 1) r += __shfl_xor(r, off, 64);
+        r = group_sum(r);
         if (i < a1 && sub == 0) {
             rho[i] = r;
             if (Q > 1) put_granule(xg + 2 * (C::XG_RHO + i), r, my_magic());
@@ -1016,37 +1044,69 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
         rho[i] = 1.0 / sr;
     }
     __syncthreads();
-    // pass 2: forces (and energy, virial) of this workgroup's atoms
+    // pass 2: forces (and energy, virial) of this workgroup's atoms.  1/r comes from v_rsq_f64 + two Newton steps (~1 ulp), which
+    // gives (a/r)^2 and a/r at once: no separate division and square root.
+    const double a1r = sqrt(a2);
     for (int i0 = a0; i0 < a1; i0 += G) {
         const int i = i0 + g;
         double ax = 0.0, ay = 0.0, az = 0.0, e = 0.0, w = 0.0, np = 0.0;
         if (i < a1) {
             const double xi = px[i], yi = py[i], zi = pz[i], isi = rho[i];
             const int c = cnt[i];
-            const unsigned long long *nb64 = (const unsigned long long *)nbr.ptr();
             const int mine = (c - sub + TPA - 1) / TPA;
-            for (int k = 0; k < mine; ++k) {
-                const unsigned long long wd = nb64[((size_t)(k >> 3) * NMAX + i) * TPA + sub];
-                const int j = (int)((wd >> (8 * (k & 7))) & 0xFFull);
-                double dx = xi - px[j], dy = yi - py[j], dz = zi - pz[j];
-                dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
-                const double r2 = dx * dx + dy * dy + dz * dz;
-                const bool in = r2 < rc2;
-                const double r2i = recip(r2);
-                const double q2 = a2 * r2i;
-                const double rm = q2 * q2 * q2;        // (a/r)^6
-                const double rn = rm * sqrt(q2);       // (a/r)^7
-                const double dF = 0.5 * cc * (isi + rho[j]);
-                const double fp = in ? eps * (7.0 * rn - 6.0 * dF * rm) * r2i : 0.0;
-                ax += dx * fp; ay += dy * fp; az += dz * fp;
-                if (WANT_E) { e += in ? eps * rn : 0.0; w += r2 * fp; np += in ? 1.0 : 0.0; }
+            for (int k0 = 0; k0 < mine; k0 += 8) {
+                const unsigned long long wd = nb64[((size_t)(k0 >> 3) * NMAX + i) * TPA + sub];
+#pragma unroll
+                for (int e0 = 0; e0 < 8; e0 += W) {
+                    if (k0 + e0 < mine) {
+                        double dx[W], dy[W], dz[W], r2[W], y[W], t[W], hh[W], msk[W], rj[W], q2[W], rm[W], rn[W], fp[W];
+#pragma unroll
+                        for (int u = 0; u < W; ++u) {
+                            const bool ok = (k0 + e0 + u) < mine;
+                            const int j = ok ? (int)((wd >> (8 * (e0 + u))) & 0xFFull) : i;
+                            dx[u] = xi - px[j]; dy[u] = yi - py[j]; dz[u] = zi - pz[j];
+                            rj[u] = rho[j];
+                            msk[u] = ok ? 1.0 : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < W; ++u) { dx[u] -= L * rint(dx[u] * invL); dy[u] -= L * rint(dy[u] * invL); dz[u] -= L * rint(dz[u] * invL); }
+#pragma unroll
+                        for (int u = 0; u < W; ++u) {
+                            r2[u] = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
+                            msk[u] = (msk[u] != 0.0 && r2[u] < rc2) ? 1.0 : 0.0;
+                            r2[u] = msk[u] != 0.0 ? r2[u] : 1.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < W; ++u) y[u] = __builtin_amdgcn_rsq(r2[u]);
+#pragma unroll
+                        for (int u = 0; u < 2 * W; ++u) { // two Newton steps per neighbour: y <- y + y (1/2 - (r2 y)(y/2))
+                            const int v = u % W;
+                            t[v] = r2[v] * y[v]; hh[v] = 0.5 * y[v];
+                            t[v] = __builtin_fma(-t[v], hh[v], 0.5);
+                            y[v] = __builtin_fma(y[v], t[v], y[v]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < W; ++u) { t[u] = y[u] * y[u]; q2[u] = a2 * t[u]; } // t = 1/r^2, q2 = (a/r)^2
+#pragma unroll
+                        for (int u = 0; u < W; ++u) { rm[u] = q2[u] * q2[u] * q2[u]; }         // (a/r)^6
+#pragma unroll
+                        for (int u = 0; u < W; ++u) { rn[u] = rm[u] * (a1r * y[u]); }           // (a/r)^7
+#pragma unroll
+                        for (int u = 0; u < W; ++u) {
+                            const double dF = 0.5 * cc * (isi + rj[u]);
+                            fp[u] = eps * (7.0 * rn[u] - 6.0 * dF * rm[u]) * t[u] * msk[u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < W; ++u) {
+                            ax += dx[u] * fp[u]; ay += dy[u] * fp[u]; az += dz[u] * fp[u];
+                            if (WANT_E) { e += eps * rn[u] * msk[u]; w += r2[u] * fp[u]; np += msk[u]; }
+                        }
+                    }
+                }
             }
         }
-#pragma unroll
-        for (int off = TPA / 2; off >= 1; off >>= 1) {
-            ax += __shfl_xor(ax, off, 64); ay += __shfl_xor(ay, off, 64); az += __shfl_xor(az, off, 64);
-            if (WANT_E) { e += __shfl_xor(e, off, 64); w += __shfl_xor(w, off, 64); np += __shfl_xor(np, off, 64); }
-        }
+        ax = group_sum(ax); ay = group_sum(ay); az = group_sum(az);
+        if (WANT_E) { e = group_sum(e); w = group_sum(w); np = group_sum(np); }
         if (i < a1 && sub == 0) {
             eacc += e; wacc += w; nacc += np;
             if (!WANT_E && fuse) { // integrate and publish on the spot, as pair_loop does (the densities' exchange took generation gen-1)
