@@ -9,7 +9,7 @@
 //   nm_block_kernel, PH_VMC     volume_mc           remcmc:552-595  (change_box ... + scaled scatter)
 //   nm_block_kernel, PH_HMC_*   hamiltonian_mc      remcmc:598-640  (Replica::hmc_velocities = velocity create/zero; fix nve run NSTPS)
 //   end of nm_block_kernel      lammps_extract      remcmc:377-391 + ratios remcmc:685-688
-//   Replica::cluster_exchange   (no counterpart)    hand-off between the workgroups that share one replica
+//   Replica::advance_and_share, exchange_sums (no counterpart)  hand-over between the workgroups that share one replica
 #pragma once
 #include "nm_device.h"
 
@@ -525,15 +525,16 @@ struct Replica {
 
     // ------------------------------------------------------------------ cluster hand-off (Q workgroups per replica)
     // Data-tagged granules (MI355X guide, hand-off price list "handoff-1to1"): every exchanged double travels as ONE
-    // 16-byte write-through (sc1) store {bits, bits ^ magic}, magic = f(launch, evaluation).  A reader polls the granule
-    // itself with sc1 loads until the two words agree with the magic of the evaluation it is in: no flag, no counter, no
+    // 16-byte write-through (sc1) store {bits, bits ^ magic}, magic = f(launch, generation).  A reader polls the granule
+    // itself with sc1 loads until the two words agree with the magic of the generation it is in: no flag, no counter, no
     // fence, one memory round trip.  A torn or stale granule fails the check (probability 2^-64 otherwise) and is re-read.
-    // Two buffers alternate; a workgroup can only run one evaluation ahead of the slowest one (it needs everybody's
-    // forces of evaluation g to finish g), so buffer g&1 is never overwritten while someone still reads it.  Spins are
-    // bounded: a cluster that is not co-resident reports ST_SYNC_TIMEOUT instead of hanging.
+    // Every exchange (positions, partial sums, EAM densities) is all-to-all and takes the next generation; two buffers
+    // alternate; a workgroup can only run one exchange ahead of the slowest one (it needs everybody's data of generation g
+    // to finish g), so buffer g&1 is never overwritten while someone still reads it.  Spins are bounded: a cluster that is
+    // not co-resident reports ST_SYNC_TIMEOUT instead of hanging.
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    // a workgroup whose own list overflowed publishes its forces under magic ^ POISON: the peers accept the granule and learn the
-    // status from it (the only status bit that is not identical in all workgroups of a cluster), so no status words are exchanged
+    // a workgroup whose own list overflowed publishes under magic ^ POISON: the peers accept the granule and learn the status
+    // from it (the only status bit that is not identical in all workgroups of a cluster), so no status words are exchanged
     static constexpr unsigned long long POISON = 0x5555555555555554ull;
     __device__ __forceinline__ unsigned long long magic() const
     {
