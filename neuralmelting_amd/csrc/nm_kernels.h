@@ -886,19 +886,22 @@ struct Replica {
     // full-system energies up to summation order)
     __device__ void delta_single(int k, double ox, double oy, double oz, double nx, double ny, double nz, double &dE, double &dW)
     {
-        const double invL = 1.0 / L, rc2 = p.rc * p.rc;
+        box_consts();
+        const double invL = bc_invL, rc2 = p.rc * p.rc;
         double s[2] = { 0.0, 0.0 };
-        for (int j = tid; j < N; j += BLOCK) {
-            if (j == k) continue;
-            const double xj = px[j], yj = py[j], zj = pz[j];
-            double dx = nx - xj, dy = ny - yj, dz = nz - zj;
+        // 2N work items: item w < N is the pair (new position, atom w), item N + w the pair (old position, atom w) with the
+        // opposite sign, so that all threads of the workgroup carry one pair each at N = 256
+        for (int w = tid; w < 2 * N; w += BLOCK) {
+            const int part = w >= N ? 1 : 0, j = w - part * N;
+            const double cx = part ? ox : nx, cy = part ? oy : ny, cz = part ? oz : nz;
+            double dx = cx - px[j], dy = cy - py[j], dz = cz - pz[j];
             dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
-            double r2 = dx * dx + dy * dy + dz * dz;
-            if (r2 < rc2) { const double r2i = 1.0 / r2, r6i = r2i * r2i * r2i; s[0] += r6i * (4.0 * r6i - 4.0); s[1] += r6i * (48.0 * r6i - 24.0); }
-            dx = ox - xj; dy = oy - yj; dz = oz - zj;
-            dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
-            r2 = dx * dx + dy * dy + dz * dz;
-            if (r2 < rc2) { const double r2i = 1.0 / r2, r6i = r2i * r2i * r2i; s[0] -= r6i * (4.0 * r6i - 4.0); s[1] -= r6i * (48.0 * r6i - 24.0); }
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            const bool in = (j != k) && r2 < rc2;
+            const double r2i = recip(in ? r2 : 1.0), r6i = r2i * r2i * r2i;
+            const double sg = in ? (part ? -1.0 : 1.0) : 0.0;
+            s[0] += sg * (r6i * (4.0 * r6i - 4.0));
+            s[1] += sg * (r6i * (48.0 * r6i - 24.0));
         }
         block_sum<2, NW, NVMAX>(s, red, parity);
         dE = s[0]; dW = s[1];
@@ -918,27 +921,46 @@ struct Replica {
                 double a = px[i], b = py[i], c = pz[i];
                 wn[3 * i] = (signed char)wrap1(a); wn[3 * i + 1] = (signed char)wrap1(b); wn[3 * i + 2] = (signed char)wrap1(c);
             }
-        __syncthreads();
         const double boxl = L;
-        for (int k = 0; k < N; ++k) {
-            nt += 1.0;
-            const double pe = U / et;
-            double u3[3];
-            if (tape) { u3[0] = draw_scalar(0, 0, 0); u3[1] = draw_scalar(0, 0, 0); u3[2] = draw_scalar(0, 0, 0); }
-            else {
+        // Philox streams are counter-based, so the N candidate positions and acceptance draws of a move do not have to be
+        // produced one trial at a time: all threads prepare them at once (atom k's own position cannot change before its
+        // trial) and park them in f[] and the saved-velocity slot, both dead during a position move.  The trial loop is then
+        // one block reduction per trial; it needs no other barrier, because the only position a trial changes is written and
+        // later read as a neighbour by the same thread (k mod BLOCK), and nobody else looks at atom k again in this move.
+        const bool pre = (tape == nullptr);
+        if (pre)
+            for (int k = tid; k < N; k += BLOCK) {
                 uint32_t o[4], q[4];
                 philox4x32_10((uint32_t)k, S_ITER_XY, m, p.step, p.seed, (uint32_t)gslot, o);
                 philox4x32_10((uint32_t)k, S_ITER_Z, m, p.step, p.seed, (uint32_t)gslot, q);
-                u3[0] = u01(o[0], o[1]); u3[1] = u01(o[2], o[3]); u3[2] = u01(q[0], q[1]);
+                double nx = px[k] + 2.0 * (u01(o[0], o[1]) - 0.5) * dx * p.lat, ny = py[k] + 2.0 * (u01(o[2], o[3]) - 0.5) * dx * p.lat,
+                       nz = pz[k] + 2.0 * (u01(q[0], q[1]) - 0.5) * dx * p.lat;
+                nx -= floor(nx / boxl) * boxl; ny -= floor(ny / boxl) * boxl; nz -= floor(nz / boxl) * boxl; // remcmc:524
+                fx[k] = nx; fy[k] = ny; fz[k] = nz;
+                svx[k] = draw_scalar(S_ITER_ACC, m, (uint32_t)k);
             }
+        __syncthreads();
+        for (int k = 0; k < N; ++k) {
+            nt += 1.0;
+            const double pe = U / et;
             const double ox = px[k], oy = py[k], oz = pz[k];
-            double nx = ox + 2.0 * (u3[0] - 0.5) * dx * p.lat, ny = oy + 2.0 * (u3[1] - 0.5) * dx * p.lat, nz = oz + 2.0 * (u3[2] - 0.5) * dx * p.lat;
-            nx -= floor(nx / boxl) * boxl; ny -= floor(ny / boxl) * boxl; nz -= floor(nz / boxl) * boxl; // remcmc:524
+            double nx, ny, nz;
+            if (pre) { nx = fx[k]; ny = fy[k]; nz = fz[k]; }
+            else {
+                const double u0 = draw_scalar(0, 0, 0), u1 = draw_scalar(0, 0, 0), u2 = draw_scalar(0, 0, 0);
+                nx = ox + 2.0 * (u0 - 0.5) * dx * p.lat; ny = oy + 2.0 * (u1 - 0.5) * dx * p.lat; nz = oz + 2.0 * (u2 - 0.5) * dx * p.lat;
+                nx -= floor(nx / boxl) * boxl; ny -= floor(ny / boxl) * boxl; nz -= floor(nz / boxl) * boxl; // remcmc:524
+            }
             double dE, dW;
             delta_single(k, ox, oy, oz, nx, ny, nz, dE, dW);
             const double Unew = U + dE;
             const double de = Unew / et - pe;
-            const bool acc = metropolis(de, S_ITER_ACC, m, (uint32_t)k);
+            bool acc;
+            if (pre) { // metropolis() with the draw made above (unused when exp(-de) overflows, as in the reference)
+                const double metcrit = exp(-de);
+                const double mm = (metcrit != metcrit) ? metcrit : (metcrit < 1.0 ? metcrit : 1.0);
+                acc = !isinf(metcrit) && svx[k] <= mm;
+            } else acc = metropolis(de, S_ITER_ACC, m, (uint32_t)k);
             crit = de;
             if (acc) { na += 1.0; ++nacc; }
             if (acc || !p.iter_revert) {
@@ -954,8 +976,9 @@ struct Replica {
                 fresh = false;
             }
             runs += acc ? 1 : 2;
-            __syncthreads();
         }
+        __syncthreads();
+        fresh = false; // f[] was used as scratch
         return nacc;
     }
 };
