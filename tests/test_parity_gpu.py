@@ -95,6 +95,35 @@ def test_block_trace_parity(oracle, bulk):
     e.close()
 
 
+@pytest.mark.parametrize('nstps', [1, 2, 3])
+@pytest.mark.parametrize('cus', [1, 2, 8])
+def test_short_trajectories_parity(oracle, monkeypatch, nstps, cus):
+    """NSTPS = 1, 2, 3 (-ts): the first / last / only steps of a trajectory take different paths through the integrator
+    hand-over (first kick outside the pair loop, middle steps fused into it, the last evaluation carrying the kinetic energy);
+    each with one, two and eight workgroups per replica"""
+    monkeypatch.setenv('NM_CUS_PER_REPLICA', str(cus))
+    sz, mod = 4, 16
+    P, T = grids(2, 2)
+    kw = dict(bulk=True, ppos=0.1, pvol=0.1, nstps=nstps)
+    loop = OracleLoop(oracle, sz, P, T, **kw)
+    e = make_engine(loop, sz, P, T, **kw)
+    assert e.cus_per_replica == cus
+    e.set_trace(True)
+    for step in range(2):
+        e.set_step(step)
+        e.run_block(mod)
+        loop.run_block(mod, step)
+        rows, ref = e.thermo(), loop.rows()
+        np.testing.assert_array_equal(rows[:, 8:14], ref[:, 8:14])
+        np.testing.assert_allclose(rows[:, :5], ref[:, :5], rtol=RTOL)
+        x, v, box, d = e.get_state()
+        np.testing.assert_allclose(x, loop.x, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(v, loop.v, rtol=0, atol=1e-8)
+        e.adapt()
+        loop.adapt()
+    e.close()
+
+
 def test_cycles_parity_with_exchange(oracle):
     """three full cycles of the main loop (remcmc:977-995): gen_samples, thermo rows, gen_mc_params, exchange"""
     sz, mod, ncyc = 4, 16, 3
