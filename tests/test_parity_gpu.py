@@ -178,13 +178,15 @@ def test_tape_replay_parity(oracle):
     e.close()
 
 
+@pytest.mark.parametrize('bulk', [True, False])
 @pytest.mark.parametrize('sz', [6, 8])
-def test_block_parity_large_cells(oracle, sz):
-    """the HBM-list kernels (6^3: 864 atoms, 8^3: 2048 atoms) against the oracle"""
+def test_block_parity_large_cells(oracle, sz, bulk):
+    """the HBM-list kernels (6^3: 864 atoms, 8^3: 2048 atoms) against the oracle, bulk and iterative position moves"""
     mod = 6
     P, T = grids(1, 2)
-    loop = OracleLoop(oracle, sz, P, T)
-    e = make_engine(loop, sz, P, T)
+    kw = dict(bulk=bulk, ppos=0.3, pvol=0.2)
+    loop = OracleLoop(oracle, sz, P, T, **kw)
+    e = make_engine(loop, sz, P, T, **kw)
     e.set_trace(True)
     e.run_block(mod)
     rows = e.thermo()
