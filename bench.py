@@ -108,6 +108,11 @@ def main():
 
     launches, kms = eng.timing()
     st = eng.stats()
+    # one more block outside the timed region, read before gen_mc_params zeroes the counters: the per-replica acceptance
+    # ratios and U, V the metric's definition asks to see next to the rate
+    eng.set_step(step)
+    eng.run_block(args.mod)
+    last = eng.thermo()
     sweeps_total = world * ns * args.mod * args.steps
     value = sweeps_total / dt
 
@@ -142,6 +147,12 @@ def main():
                      'flop_per_pair': FLOP_PER_PAIR, 'list_rebuilds_per_sweep': st[:, 1].sum() / (ns * args.mod * args.steps),
                      'cus_per_replica': eng.cus_per_replica, 'cus_occupied': ns * eng.cus_per_replica, 'cus_total': 256},
         }
+        out['replicas'] = {'note': 'rank 0, block after the timed region, slot k = i*NT + j (pressure i, temperature j)',
+                           'accept_pmc': [round(float(a), 3) for a in last[:, 14]],
+                           'accept_vmc': [round(float(a), 3) for a in last[:, 15]],
+                           'accept_hmc': [round(float(a), 3) for a in last[:, 16]],
+                           'pe_per_atom': [round(float(a) / natoms, 4) for a in last[:, 1]],
+                           'vol_per_atom': [round(float(a) / natoms, 4) for a in last[:, 4]]}
         if not args.no_cpu:
             out['cpu_baseline'] = cpu_baseline(eng, natoms, args, T, P, row0)
     if dist is not None:
