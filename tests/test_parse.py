@@ -149,3 +149,23 @@ def test_large_file_is_cut_into_ranges(tmp_path):
         rows = [ln.split() for ln in f if len(ln.split()) == 3]
     for i in sample:
         assert np.array_equal(x[i], np.array(rows[i]).astype(np.float32))
+
+
+def test_golden_from_the_reference_script(tmp_path, monkeypatch):
+    """tests/golden/ref_parse.npz holds what the reference's own lammps_parse.py (run unmodified as a child process,
+    tests/golden/make_golden_parse.py) wrote for the text stored next to it: all 20 files, bit for bit"""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_parse.npz'))
+    monkeypatch.chdir(tmp_path)
+    pre = str(tmp_path / 'g.lj.fcc.lammps')
+    np.save(pre + '.virial.trgt.npy', g['P'])
+    np.save(pre + '.temp.trgt.npy', g['T'])
+    open(pre + '.thrm', 'wb').write(g['thrm_txt'].tobytes())
+    open(pre + '.traj', 'wb').write(g['traj_txt'].tobytes())
+    parse.main(['-n', 'g', '-e', 'LJ'])
+    names = parse.COLUMNS + ('natoms', 'box', 'pos')
+    assert len(names) == 20
+    for n in names:
+        got, want = np.load(pre + '.%s.npy' % n), g['ref_' + n]
+        assert got.dtype == want.dtype and got.shape == want.shape, n
+        assert got.tobytes() == want.tobytes(), n
+    assert np.isnan(g['ref_virial']).sum() == 1          # the NAN row made it through both readers
