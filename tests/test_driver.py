@@ -146,3 +146,33 @@ def test_driver_matches_oracle_driver(tmp_path, oracle):
     ta = np.loadtxt(ra.PREF + '.thrm'); tb = np.loadtxt(rb.PREF + '.thrm')
     np.testing.assert_allclose(ta, tb, rtol=2e-4, atol=1e-4)     # the text carries 5 digits
     np.testing.assert_array_equal(ta[:, 8:14], tb[:, 8:14])
+
+
+def test_restart_file_written_by_the_reference_loads(tmp_path):
+    """tests/golden/ref_restart.npz holds the bytes of a restart file written by the REFERENCE's own dump_samples_restart
+    (remcmc:821-828, tests/golden/make_golden_restart.py): the driver's -r path reads exactly the numbers that went in, and
+    what the driver dumps has the same layout (object array NS x 21, same entry types)"""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_restart.npz'))
+    run = remcmc.Run('-r -rn gold -rs 7 -n new -e LJ -ss 2 -pn 2 -tn 2'.split(), cwd=str(tmp_path))
+    open(run.restart_file('gold', 7), 'wb').write(g['rstrt'].tobytes())
+    x, v, box, d, th = run.load_samples_restart()
+    for got, want in ((x, g['x']), (v, g['v']), (box, g['box']), (d, g['d']), (th, g['th'])):
+        assert got.dtype == np.float64 and np.array_equal(got, want)
+    ref = list(np.load(run.restart_file('gold', 7), allow_pickle=True))
+    # the driver's own dump of the same state: same shape, same kinds of entries
+    class Eng:
+        nslots, natoms = 4, 32
+        def get_state(self, **k): return x, v, box, d
+        def thermo(self):
+            rows = np.zeros((4, 17)); rows[:, :5] = th[:, [0, 1, 2, 3, 4]]; rows[:, 5:8] = d
+            return rows
+    run.engine = Eng()
+    run.STEP = 0
+    run.dump_samples_restart()
+    mine = list(np.load(run.restart_file('new', 1), allow_pickle=True))
+    assert len(mine) == len(ref) == 4
+    for a, b in zip(mine, ref):
+        assert len(a) == len(b) == 21 and a[0] == b[0] == 32
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert [float(a[i]) for i in range(3, 12)] == [float(b[i]) for i in range(3, 12)]
+        assert [float(q) for q in a[12:]] == [0.0] * 9 == [float(q) for q in b[12:]]      # counters and ratios are zero after gen_mc_param
