@@ -176,3 +176,21 @@ def test_restart_file_written_by_the_reference_loads(tmp_path):
         assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
         assert [float(a[i]) for i in range(3, 12)] == [float(b[i]) for i in range(3, 12)]
         assert [float(q) for q in a[12:]] == [0.0] * 9 == [float(q) for q in b[12:]]      # counters and ratios are zero after gen_mc_param
+
+
+def test_output_files_equal_the_references(tmp_path):
+    """tests/golden/ref_outputs.npz: the consolidated .thrm / .traj the REFERENCE's own init_outputs, init_headers,
+    write_outputs and consolidate_outputs leave for three recorded cycles of a 2x3 grid (tests/golden/make_golden_outputs.py).
+    The driver's writer (headers in Python, rows and frames through nm_append_outputs, chunked consolidation) must leave the
+    same bytes."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_outputs.npz'))
+    npn, ntn, sz, ncyc = [int(q) for q in g['shape']]
+    run = remcmc.Run(('-n gout -e LJ -ss %d -pn %d -tn %d -sn 5 -sc 2 -sm 16' % (sz, npn, ntn)).split(), cwd=str(tmp_path))
+    run.init_outputs()
+    run.init_headers()
+    for c in range(ncyc):
+        run.write_outputs(g['rows'][c], g['x'][c], g['box'][c])
+    run.consolidate_outputs()
+    assert open(run.PREF + '.thrm', 'rb').read() == g['thrm'].tobytes()
+    assert open(run.PREF + '.traj', 'rb').read() == g['traj'].tobytes()
+    assert sorted(os.listdir(tmp_path)) == ['gout.lj.fcc.lammps.thrm', 'gout.lj.fcc.lammps.traj']
