@@ -83,7 +83,11 @@ struct Cfg {
     static constexpr size_t A3 = (size_t)3 * NMAX * sizeof(double);
     static constexpr size_t OFF_POS = 0, OFF_VEL = A3, OFF_FRC = 2 * A3;
     static constexpr size_t OFF_SAV = 3 * A3, OFF_SAVV = 4 * A3, OFF_X0 = 5 * A3; // only when SAVE_LDS
-    static constexpr size_t OFF_RED = SAVE_LDS ? 6 * A3 : 3 * A3;
+    // saved forces (small systems only: 6 KB): a rejected move then also gets its forces back, and a trajectory that follows it
+    // starts without re-evaluating the restored configuration
+    static constexpr bool SAVE_F = SAVE_LDS && NMAX <= 256;
+    static constexpr size_t OFF_SAVF = 6 * A3;
+    static constexpr size_t OFF_RED = SAVE_LDS ? (SAVE_F ? 7 * A3 : 6 * A3) : 3 * A3;
     static constexpr size_t OFF_CNT = OFF_RED + (size_t)2 * NW * NVMAX * sizeof(double);
     // image flags (int16) and the iter-PMC wrap counts (int8): in LDS with the saved copies, else in the global spill
     static constexpr size_t OFF_IMG = OFF_CNT + pad8((size_t)NMAX * sizeof(unsigned short));
@@ -131,6 +135,7 @@ struct Replica {
     typename ArrSel<C::SAVE_LDS, double, C::OFF_SAV + 2 * A1>::type sz;
     typename ArrSel<C::SAVE_LDS, double, C::OFF_SAVV>::type svx; typename ArrSel<C::SAVE_LDS, double, C::OFF_SAVV + A1>::type svy;
     typename ArrSel<C::SAVE_LDS, double, C::OFF_SAVV + 2 * A1>::type svz;
+    LdsArr<double, C::OFF_SAVF> sfx; LdsArr<double, C::OFF_SAVF + A1> sfy; LdsArr<double, C::OFF_SAVF + 2 * A1> sfz; // when C::SAVE_F
     typename ArrSel<C::SAVE_LDS, double, C::OFF_X0>::type x0; typename ArrSel<C::SAVE_LDS, double, C::OFF_X0 + A1>::type y0;
     typename ArrSel<C::SAVE_LDS, double, C::OFF_X0 + 2 * A1>::type z0;
     typename ArrSel<C::SAVE_LDS, short, C::OFF_IMG>::type im;      // LAMMPS image flags
@@ -147,7 +152,11 @@ struct Replica {
     double bc_L = -1.0, bc_L0 = -1.0, bc_invL = 0.0, bc_sc = 0.0, bc_thr2 = 0.0;
     bool bc_bad = true;
     double psum[3] = { 0.0, 0.0, 0.0 }; // partial (then cluster-wide) sums of the last energy evaluation: 2U, 2W, 2 pairs
-    bool list_ok = false, fresh = false;
+    // block-uniform flags in ONE scalar register (three separate bools cost lane masks and spilled scalars in the hot loops)
+    enum : int { F_LIST_OK = 1, F_FRESH = 2, F_SAVED_FRESH = 4 };
+    int flags = 0;
+    __device__ __forceinline__ bool fresh() const { return (flags & F_FRESH) != 0; }
+    __device__ __forceinline__ void set_fresh(bool b) { flags = b ? (flags | F_FRESH) : (flags & ~F_FRESH); }
     int status = 0;
     const double *tape = nullptr;
     int tpos = 0, tlen = 0;
@@ -264,14 +273,27 @@ struct Replica {
             sx[i] = px[i]; sy[i] = py[i]; sz[i] = pz[i];
             if (with_v) { svx[i] = vx[i]; svy[i] = vy[i]; svz[i] = vz[i]; }
         }
+        if constexpr (C::SAVE_F) { // the forces of the own atoms, if they belong to these positions
+            flags = fresh() ? (flags | F_SAVED_FRESH) : (flags & ~F_SAVED_FRESH);
+            if (fresh())
+                for (int i = a0 + tid; i < a1; i += BLOCK) { sfx[i] = fx[i]; sfy[i] = fy[i]; sfz[i] = fz[i]; }
+        }
     }
+    // The reference answers a rejection with scatter_atoms + `run 0`, i.e. it re-evaluates the old configuration.  The result
+    // is what was there before the move (the caller puts U, W back); where the forces were saved too they come back as well and
+    // the configuration counts as evaluated: a trajectory that follows starts from them.
     __device__ void restore(bool with_v)
     {
         for (int i = tid; i < N; i += BLOCK) {
             px[i] = sx[i]; py[i] = sy[i]; pz[i] = sz[i]; // scatter_atoms: x only, LAMMPS image flags keep what the remaps did
             if (with_v) { vx[i] = svx[i]; vy[i] = svy[i]; vz[i] = svz[i]; }
         }
-        fresh = false;
+        set_fresh(false);
+        if constexpr (C::SAVE_F)
+            if (flags & F_SAVED_FRESH) {
+                for (int i = a0 + tid; i < a1; i += BLOCK) { fx[i] = sfx[i]; fy[i] = sfy[i]; fz[i] = sfz[i]; }
+                set_fresh(true);
+            }
     }
     __device__ double sum_mv2()
     {
@@ -338,7 +360,7 @@ struct Replica {
         }
         for (int i = tid; i < N; i += BLOCK) { x0[i] = px[i]; y0[i] = py[i]; z0[i] = pz[i]; }
         L0 = L;
-        list_ok = true;
+        flags |= F_LIST_OK;
         if (p.inj_rebuild >= 0 && (int)st_rebuilds == p.inj_rebuild && q == p.inj_q % Q) ovf = 1; // fault injection (tests)
         st_rebuilds += 1.0;
         if (block_any<NW, NVMAX>(ovf != 0, red, parity)) status |= ST_LIST_OVERFLOW;
@@ -726,7 +748,7 @@ struct Replica {
             }
             ++gen;
         }
-        fresh = false;
+        set_fresh(false);
         const int fl = block_any3<NW, NVMAX>(timeout != 0, poisoned != 0, c.bad != 0, red, parity);
         if (fl & 1) status |= ST_SYNC_TIMEOUT;
         if (fl & 2) status |= ST_LIST_OVERFLOW;
@@ -743,7 +765,7 @@ struct Replica {
     {
         if (status & (ST_SYNC_TIMEOUT | ST_LIST_OVERFLOW)) return; // learnt from the last hand-over: the cluster is leaving
         if (!(L >= 2.0 * p.rc)) { status |= ST_BOX_TOO_SMALL; __syncthreads(); return; } // minimum-image limit
-        bool need = !list_ok;
+        bool need = !(flags & F_LIST_OK);
         TLINE(0);
         PROF_BEGIN();
         // The validity check reads only a thread's own atoms (written by itself) and x0 (settled since the last rebuild), so
@@ -782,7 +804,7 @@ struct Replica {
         TLINE(4);
         if (want_e) { psum[0] = s[0]; psum[1] = s[1]; psum[2] = s[2]; }
         ++tl_n;
-        fresh = true;
+        set_fresh(true);
     }
 
     __device__ void take_sums()
@@ -973,12 +995,12 @@ struct Replica {
                     }
                 }
                 U = Unew; W += dW;
-                fresh = false;
+                set_fresh(false);
             }
             runs += acc ? 1 : 2;
         }
         __syncthreads();
-        fresh = false; // f[] was used as scratch
+        set_fresh(false); // f[] was used as scratch
         return nacc;
     }
 };
@@ -1317,7 +1339,7 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
                     R.py[i] += a * 2.0 * (u01(o[2], o[3]) - 0.5);
                     R.pz[i] += a * 2.0 * (u01(q[0], q[1]) - 0.5);
                 }
-                R.fresh = false;
+                R.set_fresh(false);
                 R.wrap();
                 phase = PH_BULK; want_e = true; pending = true;
                 PROF_END(10);
@@ -1340,7 +1362,7 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
                 const double boxnew = cbrt(c_volnew);
                 const double scale = boxnew / c_boxl;
                 for (int i = tid; i < N; i += BLOCK) { R.px[i] = scale * R.sx[i]; R.py[i] = scale * R.sy[i]; R.pz[i] = scale * R.sz[i]; }
-                R.fresh = false;
+                R.set_fresh(false);
                 R.L = uniform(q6(boxnew)); // change_box ... %f
                 R.wrap();
                 phase = PH_VMC; want_e = true; pending = true;
@@ -1353,7 +1375,7 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
                 c_dtfm = 0.5 * c_h * p.ftm2v / p.mass;
                 R.wrap(); // run 0
                 phase = PH_HMC_START; want_e = true; pending = true;
-                skip_eval = R.fresh; // nothing moved since the last evaluation: same U, W, f
+                skip_eval = R.fresh(); // nothing moved since the last evaluation: same U, W, f
                 PROF_END(12);
             }
         }
