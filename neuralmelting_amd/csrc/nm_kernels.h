@@ -88,7 +88,11 @@ struct Cfg {
     static constexpr bool SAVE_F = SAVE_LDS && NMAX <= 256;
     static constexpr size_t OFF_SAVF = 6 * A3;
     static constexpr size_t OFF_RED = SAVE_LDS ? (SAVE_F ? 7 * A3 : 6 * A3) : 3 * A3;
-    static constexpr size_t OFF_CNT = OFF_RED + (size_t)2 * NW * NVMAX * sizeof(double);
+    // per-wave copies of block-uniform scalars that are touched once per move (counters, the move's saved energies, the slot's
+    // constants): kept in LDS instead of ~40 scalar registers that the hot loops would otherwise spill and reload
+    static constexpr int UST_PER_WAVE = 32;
+    static constexpr size_t OFF_UST = OFF_RED + (size_t)2 * NW * NVMAX * sizeof(double);
+    static constexpr size_t OFF_CNT = OFF_UST + (size_t)NW * UST_PER_WAVE * sizeof(double);
     // image flags (int16) and the iter-PMC wrap counts (int8): in LDS with the saved copies, else in the global spill
     static constexpr size_t OFF_IMG = OFF_CNT + pad8((size_t)NMAX * sizeof(unsigned short));
     static constexpr size_t OFF_WN = OFF_IMG + pad8((size_t)3 * NMAX * sizeof(short));
@@ -152,6 +156,8 @@ struct Replica {
     double bc_L = -1.0, bc_L0 = -1.0, bc_invL = 0.0, bc_sc = 0.0, bc_thr2 = 0.0;
     bool bc_bad = true;
     double psum[3] = { 0.0, 0.0, 0.0 }; // partial (then cluster-wide) sums of the last energy evaluation: 2U, 2W, 2 pairs
+    // slot k of this wave's copy of the rarely-touched uniform scalars (every lane of the wave reads / writes the same value)
+    __device__ __forceinline__ double &ust(int k) const { return ((double *)(nm_lds + C::OFF_UST))[(tid >> 6) * C::UST_PER_WAVE + k]; }
     // block-uniform flags in ONE scalar register (three separate bools cost lane masks and spilled scalars in the hot loops)
     enum : int { F_LIST_OK = 1, F_FRESH = 2, F_SAVED_FRESH = 4 };
     int flags = 0;
@@ -1205,10 +1211,15 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
     R.L = uniform(p.eval_only ? p.box[buf] : q6(p.box[buf]));
     R.wrap();
 
-    const double et = p.et[slot], pf = p.pf[slot], t = p.tq[slot];
-    const double dx = p.steps[3 * buf], dv = p.steps[3 * buf + 1], dt = p.steps[3 * buf + 2];
-    double ntp = p.count[6 * slot], nap = p.count[6 * slot + 1], ntv = p.count[6 * slot + 2];
-    double nav = p.count[6 * slot + 3], nth = p.count[6 * slot + 4], nah = p.count[6 * slot + 5];
+    // uniform scalars that are touched once per move live in LDS (Replica::ust), not in scalar registers
+    double &et = R.ust(0), &pf = R.ust(1), &t = R.ust(2), &dx = R.ust(3), &dv = R.ust(4), &dt = R.ust(5);
+    double &ntp = R.ust(6), &nap = R.ust(7), &ntv = R.ust(8), &nav = R.ust(9), &nth = R.ust(10), &nah = R.ust(11);
+    double &U0 = R.ust(12), &W0 = R.ust(13), &c_pe = R.ust(14), &c_vol = R.ust(15), &c_volnew = R.ust(16), &c_boxl = R.ust(17);
+    et = p.et[slot]; pf = p.pf[slot]; t = p.tq[slot];
+    dx = p.steps[3 * buf]; dv = p.steps[3 * buf + 1]; dt = p.steps[3 * buf + 2];
+    ntp = p.count[6 * slot]; nap = p.count[6 * slot + 1]; ntv = p.count[6 * slot + 2];
+    nav = p.count[6 * slot + 3]; nth = p.count[6 * slot + 4]; nah = p.count[6 * slot + 5];
+    U0 = 0.0; W0 = 0.0; c_pe = 0.0; c_vol = 0.0; c_volnew = 0.0; c_boxl = 0.0;
     const int fatal = ST_BOX_TOO_SMALL | ST_LIST_OVERFLOW | ST_SYNC_TIMEOUT;
 
     // state carried across the evaluation of a move
@@ -1216,7 +1227,7 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
     bool want_e = true, skip_eval = false;
     double mv2new = 0.0; // kinetic-energy sum delivered with the last evaluation of a trajectory
     bool have_need = false, pre_need = false; // rebuild decision delivered with a position hand-over (HMC steps)
-    double U0 = 0.0, W0 = 0.0, c_pe = 0.0, c_vol = 0.0, c_volnew = 0.0, c_boxl = 0.0, c_h = 0.0, c_dtfm = 0.0;
+    double c_h = 0.0, c_dtfm = 0.0;
 
     for (;;) {
         const int st_before = R.status;
