@@ -187,11 +187,16 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red, int &par
         if (lane == 0) r[wv * NVMAX + q] = s;
     }
     __syncthreads();
+    // second stage: lane q < NV of every wave adds the NW partial sums of value q (NW reads instead of NW*NV per thread), then
+    // the totals are handed to all lanes through v_readlane: scalar registers, the same bits everywhere
+    double s = 0.0;
+    if (lane < NV)
+        for (int w = 0; w < NW; ++w) s += r[w * NVMAX + lane];
+    const long long sb = __double_as_longlong(s);
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
-        double s = 0.0;
-        for (int w = 0; w < NW; ++w) s += r[w * NVMAX + q];
-        v[q] = uniform(s);
+        const uint32_t lo = __builtin_amdgcn_readlane((int)sb, q), hi = __builtin_amdgcn_readlane((int)(sb >> 32), q);
+        v[q] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
     }
     parity ^= 1;
 }
