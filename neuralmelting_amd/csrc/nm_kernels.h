@@ -1225,9 +1225,11 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
     // state carried across the evaluation of a move
     int phase = PH_INIT, m = 0, hstep = 0;
     bool want_e = true, skip_eval = false;
-    double mv2new = 0.0; // kinetic-energy sum delivered with the last evaluation of a trajectory
+    double &mv2new = R.ust(18); // kinetic-energy sum delivered with the last evaluation of a trajectory
+    mv2new = 0.0;
     bool have_need = false, pre_need = false; // rebuild decision delivered with a position hand-over (HMC steps)
-    double c_h = 0.0, c_dtfm = 0.0;
+    double &c_h = R.ust(19), &c_dtfm = R.ust(20);
+    c_h = 0.0; c_dtfm = 0.0;
 
     for (;;) {
         const int st_before = R.status;
