@@ -142,7 +142,13 @@ def main():
                          'algorithmic_bytes_per_launch': bytes_per_sweep * sweeps_per_launch,
                          'note': 'LDS-resident by design: the binding ceiling is fp64 VALU/latency on the CUs that hold a '
                                  'replica, see fp64'},
+            # executed work (evaluations the kernel really made) and SURVEY.md §8d's algorithmic count
+            # EVALS = PPOS + PVOL + PHMC (NSTPS + 1) = 7.0 per sweep at the defaults (the kernel makes fewer: forces are kept
+            # across accepted and rejected moves)
             'fp64': {'achieved': tf, 'peak': FP64_VEC_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tf / FP64_VEC_PEAK_TF,
+                     'algorithmic_evals_per_sweep': 0.125 + 0.125 + phmc * 9.0,
+                     'achieved_algorithmic': (0.125 + 0.125 + phmc * 9.0) * sweeps_per_launch * mean_pairs * FLOP_PER_PAIR
+                                             / k_avg_s / 1e12,
                      'evals_per_sweep': evals / (ns * args.mod * args.steps), 'mean_pairs_per_eval': mean_pairs,
                      'flop_per_pair': FLOP_PER_PAIR, 'list_rebuilds_per_sweep': st[:, 1].sum() / (ns * args.mod * args.steps),
                      'cus_per_replica': eng.cus_per_replica, 'cus_occupied': ns * eng.cus_per_replica, 'cus_total': 256},
