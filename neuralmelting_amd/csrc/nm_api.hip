@@ -37,7 +37,8 @@ typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 256, unsigned char, true, tru
 typedef Cfg<512, 1, 864, 160, unsigned short, false, true> CfgMid;     // N <= 864: list in HBM/L2, saved copies in LDS
 typedef Cfg<512, 1, 864, 160, unsigned short, false, true> CfgMidQ2;   // cluster variants: own atoms 432 / 216 / 108
 typedef Cfg<512, 2, 864, 160, unsigned short, false, true> CfgMidQ4;
-typedef Cfg<512, 4, 864, 160, unsigned short, false, true> CfgMidQ8;
+// 8 workgroups per replica: 108 own atoms, whose list rows (16-bit, 35 KB) fit in LDS once the saved velocities moved to the spill
+typedef Cfg<512, 4, 864, 160, unsigned short, true, true, 0, 108, false> CfgMidQ8;
 typedef Cfg<512, 1, 2048, 160, unsigned short, false, false> CfgLarge; // N <= 2048: saved copies spill to HBM as well
 
 thread_local std::string g_create_error;
@@ -276,6 +277,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
         const int maxq = c->kind == 0 ? (c->pot == 0 ? 8 : 4) : c->kind == 1 ? 8 : 2; // own-atom ranges the instantiated thread mappings cover
         for (int qq : { 8, 4, 2 })
             if (qq <= maxq && want >= qq && c->nslots * qq <= cu) { c->cus = qq; break; }
+        if (c->kind == 1 && c->cus == 8) { c->aux_doubles = CfgMidQ8::AUX_DOUBLES; c->lds_bytes = CfgMidQ8::LDS_BYTES; }
     }
     const size_t ns = c->nslots, n3 = (size_t)3 * c->N;
     CHK(dalloc(&c->d_x, ns * n3)); CHK(dalloc(&c->d_v, ns * n3));
@@ -322,9 +324,10 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
         CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallSCQ4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmallSC::LDS_BYTES));
     }
     else if (c->kind == 1) {
-        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgMid>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
-        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgMidQ4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
-        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgMidQ8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgMid>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgMid::LDS_BYTES));
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgMidQ4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgMidQ4::LDS_BYTES));
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgMidQ8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgMidQ8::LDS_BYTES));
+        static_assert(CfgMidQ8::LDS_BYTES <= 160 * 1024, "the 6^3 cluster configuration must fit the CU's LDS");
     }
     else CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgLarge>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
     c->ev.resize(32);

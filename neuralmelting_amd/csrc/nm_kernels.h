@@ -73,8 +73,16 @@ template <typename T, size_t OFF> struct ArrSel<false, T, OFF> { using type = Gl
 // NMAX (array stride) and MAXNB (neighbour slots per atom) are compile-time so that every LDS array sits at a
 // constant offset: no address registers are needed for them (with run-time strides the eighteen array bases were
 // spilled to scratch and reloaded inside the pair loop).
-template <int BLOCK_, int TPA_, int NMAX_, int MAXNB_, typename IdxT_, bool LIST_LDS_, bool SAVE_LDS_, int POT_ = 0>
+template <int BLOCK_, int TPA_, int NMAX_, int MAXNB_, typename IdxT_, bool LIST_LDS_, bool SAVE_LDS_, int POT_ = 0, int NLIST_ = NMAX_,
+          bool SAVEV_LDS_ = SAVE_LDS_>
 struct Cfg {
+    // NLIST: rows of an LDS list.  A workgroup only builds and reads the rows of its own atoms; a cluster configuration whose own
+    // range is a fixed fraction of NMAX stores just those (row = i - a0).  SAVEV_LDS: the saved velocities (touched twice per
+    // HMC move) may live in the global spill while the saved positions and the list reference stay in LDS — together these two
+    // make room for the list of the 6^3 system at 8 workgroups per replica.
+    static constexpr int NLIST = NLIST_;
+    static constexpr bool SAVEV_LDS = SAVEV_LDS_;
+    static_assert(SAVE_LDS_ || !SAVEV_LDS_, "saved velocities in LDS only together with the saved positions");
     static constexpr int POT = POT_; // 0 = lj/cut 2.5, 1 = Sutton-Chen EAM (two-pass: densities, then forces)
     static constexpr int BLOCK = BLOCK_, TPA = TPA_, NW = BLOCK_ / 64, G = BLOCK_ / TPA_, NMAX = NMAX_, MAXNB = MAXNB_;
     static constexpr bool LIST_LDS = LIST_LDS_, SAVE_LDS = SAVE_LDS_;
@@ -82,12 +90,13 @@ struct Cfg {
     static constexpr size_t pad8(size_t n) { return (n + 7) & ~(size_t)7; }
     static constexpr size_t A3 = (size_t)3 * NMAX * sizeof(double);
     static constexpr size_t OFF_POS = 0, OFF_VEL = A3, OFF_FRC = 2 * A3;
-    static constexpr size_t OFF_SAV = 3 * A3, OFF_SAVV = 4 * A3, OFF_X0 = 5 * A3; // only when SAVE_LDS
+    static constexpr size_t OFF_SAV = 3 * A3, OFF_SAVV = 4 * A3, OFF_X0 = (SAVEV_LDS ? 5 : 4) * A3; // only when SAVE_LDS (/ SAVEV_LDS)
     // saved forces (small systems only: 6 KB): a rejected move then also gets its forces back, and a trajectory that follows it
     // starts without re-evaluating the restored configuration
     static constexpr bool SAVE_F = SAVE_LDS && NMAX <= 256;
     static constexpr size_t OFF_SAVF = 6 * A3;
-    static constexpr size_t OFF_RED = SAVE_LDS ? (SAVE_F ? 7 * A3 : 6 * A3) : 3 * A3;
+    static_assert(!SAVE_F || SAVEV_LDS, "");
+    static constexpr size_t OFF_RED = (3 + (SAVE_LDS ? 2 : 0) + (SAVEV_LDS ? 1 : 0) + (SAVE_F ? 1 : 0)) * A3;
     // per-wave copies of block-uniform scalars that are touched once per move (counters, the move's saved energies, the slot's
     // constants): kept in LDS instead of ~40 scalar registers that the hot loops would otherwise spill and reload
     static constexpr int UST_PER_WAVE = 32;
@@ -97,10 +106,10 @@ struct Cfg {
     static constexpr size_t OFF_IMG = OFF_CNT + pad8((size_t)NMAX * sizeof(unsigned short));
     static constexpr size_t OFF_WN = OFF_IMG + pad8((size_t)3 * NMAX * sizeof(short));
     static constexpr size_t OFF_NBR = SAVE_LDS ? OFF_WN + pad8((size_t)3 * NMAX) : OFF_IMG;
-    static constexpr size_t OFF_RHO = LIST_LDS ? OFF_NBR + pad8((size_t)MAXNB * NMAX * sizeof(IdxT)) : OFF_NBR; // EAM densities
+    static constexpr size_t OFF_RHO = LIST_LDS ? OFF_NBR + pad8((size_t)MAXNB * NLIST * sizeof(IdxT)) : OFF_NBR; // EAM densities
     static constexpr size_t LDS_BYTES = OFF_RHO + (POT ? (size_t)NMAX * sizeof(double) : 0);
     // per-slot global spill when the saved copies do not fit in LDS: sav, savv, x0 (9 NMAX doubles) + images + wrap counts
-    static constexpr size_t AUX_DOUBLES = SAVE_LDS ? 0 : (size_t)9 * NMAX + ((size_t)3 * NMAX * 3 + 7) / 8;
+    static constexpr size_t AUX_DOUBLES = SAVE_LDS ? (SAVEV_LDS ? 0 : (size_t)3 * NMAX) : (size_t)9 * NMAX + ((size_t)3 * NMAX * 3 + 7) / 8;
     static constexpr size_t NBR_G_ELEMS = LIST_LDS ? 0 : (size_t)MAXNB * NMAX; // per-slot global list
     // Lists that live in HBM/L2 are stored in chunks of CH consecutive neighbours of one atom ([chunk][atom][CH]) so that one
     // 8-byte load brings four indices: the dependent L2 round trip per neighbour was the cost there.  LDS lists stay [slot][atom].
@@ -110,7 +119,10 @@ struct Cfg {
     // ds_read_b64: neighbour slot r of atom i belongs to thread sub = r % TPA as its k-th neighbour (k = r / TPA) and sits at byte
     // (((k / 8) * NMAX + i) * TPA + sub) * 8 + k % 8.  (One ds_read_u8 per neighbour was an 8-way bank conflict: the 8 threads of
     // an atom read rows 256 B apart; with the three position gathers it made the pair loop LDS-bound, scripts/ubench_pair.hip.)
-    static_assert(!LIST_LDS || (sizeof(IdxT) == 1 && MAXNB % (8 * TPA) == 0), "LDS lists: bytes, MAXNB a multiple of 8*TPA");
+    // 16-bit indices (N > 256) use the same layout with four entries per 8-byte word.
+    static constexpr int PW = 8 / (int)sizeof(IdxT); // list entries per 8-byte word
+    static constexpr int LOG2PW = sizeof(IdxT) == 1 ? 3 : 2;
+    static_assert(!LIST_LDS || ((sizeof(IdxT) == 1 || sizeof(IdxT) == 2) && MAXNB % (PW * TPA) == 0), "LDS lists: MAXNB a multiple of PW*TPA");
     static constexpr int QMAX = 8;                                               // most workgroups per replica
     static constexpr size_t XBUF_GRANULES = (size_t)4 * NMAX + 4 * QMAX;         // forces by component, EAM densities, per-workgroup partials
     static constexpr size_t XG_PART = (size_t)3 * NMAX, XG_RHO = (size_t)3 * NMAX + 4 * QMAX; // granule indices
@@ -137,8 +149,8 @@ struct Replica {
     // saved positions / velocities, list reference positions, image flags, wrap counts: LDS or the per-workgroup global spill
     typename ArrSel<C::SAVE_LDS, double, C::OFF_SAV>::type sx; typename ArrSel<C::SAVE_LDS, double, C::OFF_SAV + A1>::type sy;
     typename ArrSel<C::SAVE_LDS, double, C::OFF_SAV + 2 * A1>::type sz;
-    typename ArrSel<C::SAVE_LDS, double, C::OFF_SAVV>::type svx; typename ArrSel<C::SAVE_LDS, double, C::OFF_SAVV + A1>::type svy;
-    typename ArrSel<C::SAVE_LDS, double, C::OFF_SAVV + 2 * A1>::type svz;
+    typename ArrSel<C::SAVEV_LDS, double, C::OFF_SAVV>::type svx; typename ArrSel<C::SAVEV_LDS, double, C::OFF_SAVV + A1>::type svy;
+    typename ArrSel<C::SAVEV_LDS, double, C::OFF_SAVV + 2 * A1>::type svz;
     LdsArr<double, C::OFF_SAVF> sfx; LdsArr<double, C::OFF_SAVF + A1> sfy; LdsArr<double, C::OFF_SAVF + 2 * A1> sfz; // when C::SAVE_F
     typename ArrSel<C::SAVE_LDS, double, C::OFF_X0>::type x0; typename ArrSel<C::SAVE_LDS, double, C::OFF_X0 + A1>::type y0;
     typename ArrSel<C::SAVE_LDS, double, C::OFF_X0 + 2 * A1>::type z0;
@@ -184,6 +196,10 @@ struct Replica {
             x0.g = a + 6 * (size_t)NMAX; y0.g = a + 7 * (size_t)NMAX; z0.g = a + 8 * (size_t)NMAX;
             im.g = (short *)(a + 9 * (size_t)NMAX);
             wn.g = (signed char *)(im.g + 3 * (size_t)NMAX);
+        }
+        else if constexpr (!C::SAVEV_LDS) {
+            double *a = p.aux_g + ((size_t)slot * p.cus + q_) * C::AUX_DOUBLES;
+            svx.g = a; svy.g = a + NMAX; svz.g = a + 2 * (size_t)NMAX;
         }
         if constexpr (!C::LIST_LDS) nbr.g = (IdxT *)p.nbr_g + (size_t)slot * C::NBR_G_ELEMS;
         if (p.tape) { tape = p.tape + p.tape_off[slot]; tlen = p.tape_off[slot + 1] - p.tape_off[slot]; }
@@ -321,10 +337,12 @@ struct Replica {
     // ------------------------------------------------------------------ Verlet list
     // Wave-cooperative build: one wave per atom i, 64 candidate j per step, ballot compaction keeps the
     // list sorted by j, so the list (and every sum over it) is independent of scheduling.
+    // row of atom i in an LDS list
+    __device__ __forceinline__ int lrow(int i) const { return C::NLIST == NMAX ? i : i - a0; }
     // element index of neighbour slot r of atom i in the list
     __device__ __forceinline__ size_t nbr_at(int r, int i) const
     {
-        if constexpr (C::LIST_LDS) { const int sub = r % TPA, k = r / TPA; return ((((size_t)(k >> 3) * NMAX + i) * TPA + sub) << 3) + (k & 7); }
+        if constexpr (C::LIST_LDS) { const int sub = r % TPA, k = r / TPA; return ((((size_t)(k >> C::LOG2PW) * C::NLIST + lrow(i)) * TPA + sub) << C::LOG2PW) + (k & (C::PW - 1)); }
         else return ((size_t)(r / C::CH) * NMAX + i) * C::CH + (r % C::CH);
     }
 
@@ -466,20 +484,21 @@ struct Replica {
                 const double xi = px[i], yi = py[i], zi = pz[i];
                 const int c = cnt[i];
                 if constexpr (C::LIST_LDS) {
-                    constexpr int W = NM_PAIR_W;
+                    constexpr int W = NM_PAIR_W, PW = C::PW, BITS = 8 * (int)sizeof(IdxT);
+                    static_assert(PW % W == 0, "");
                     const unsigned long long *nb64 = (const unsigned long long *)nbr.ptr();
                     const int mine = (c - sub + TPA - 1) / TPA; // neighbours of atom i that this thread handles: slots sub, sub+TPA, ...
-                    for (int k0 = 0; k0 < mine; k0 += 8) {      // one conflict-free 8-byte read = eight of them
-                        const unsigned long long wd = nb64[((size_t)(k0 >> 3) * NMAX + i) * TPA + sub];
+                    for (int k0 = 0; k0 < mine; k0 += PW) {     // one conflict-free 8-byte read = PW of them
+                        const unsigned long long wd = nb64[((size_t)(k0 >> C::LOG2PW) * C::NLIST + lrow(i)) * TPA + sub];
 #pragma unroll
-                        for (int e0 = 0; e0 < 8; e0 += W) {
+                        for (int e0 = 0; e0 < PW; e0 += W) {
                             if (k0 + e0 < mine) {
                                 int jj[W];
                                 bool ok[W];
 #pragma unroll
                                 for (int q = 0; q < W; ++q) {
                                     ok[q] = (k0 + e0 + q) < mine;
-                                    jj[q] = ok[q] ? (int)((wd >> (8 * (e0 + q))) & 0xFFull) : i; // a masked lane looks at itself: finite, ignored
+                                    jj[q] = ok[q] ? (int)((wd >> (BITS * (e0 + q))) & ((1ull << BITS) - 1ull)) : i; // a masked lane looks at itself: finite, ignored
                                 }
                                 pair_vec<WANT_E, W>(jj, ok, xi, yi, zi, invL, rc2, ax, ay, az, e, w, np);
                             }
@@ -1022,6 +1041,7 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
     // pass 1: densities of this workgroup's atoms.  Both passes walk the byte list like pair_loop does: one conflict-free 8-byte
     // read = eight neighbours, two neighbours' dependency chains interleaved stage by stage.
     constexpr int W = NM_PAIR_W;
+    static_assert(sizeof(IdxT) == 1 && C::NLIST == NMAX, "the EAM loops read byte lists with one row per atom");
     const unsigned long long *nb64 = (const unsigned long long *)nbr.ptr();
     for (int i0 = a0; i0 < a1; i0 += G) {
         const int i = i0 + g;
