@@ -91,12 +91,12 @@ struct Cfg {
     static constexpr size_t A3 = (size_t)3 * NMAX * sizeof(double);
     static constexpr size_t OFF_POS = 0, OFF_VEL = A3, OFF_FRC = 2 * A3;
     static constexpr size_t OFF_SAV = 3 * A3, OFF_SAVV = 4 * A3, OFF_X0 = (SAVEV_LDS ? 5 : 4) * A3; // only when SAVE_LDS (/ SAVEV_LDS)
-    // saved forces (small systems only: 6 KB): a rejected move then also gets its forces back, and a trajectory that follows it
-    // starts without re-evaluating the restored configuration
-    static constexpr bool SAVE_F = SAVE_LDS && NMAX <= 256;
+    // saved forces: a rejected move then also gets its forces back, and a trajectory that follows it starts without
+    // re-evaluating the restored configuration.  In LDS for the small systems (6 KB), in the global spill otherwise.
+    static constexpr bool SAVEF_LDS = SAVE_LDS && NMAX <= 256;
     static constexpr size_t OFF_SAVF = 6 * A3;
-    static_assert(!SAVE_F || SAVEV_LDS, "");
-    static constexpr size_t OFF_RED = (3 + (SAVE_LDS ? 2 : 0) + (SAVEV_LDS ? 1 : 0) + (SAVE_F ? 1 : 0)) * A3;
+    static_assert(!SAVEF_LDS || SAVEV_LDS, "");
+    static constexpr size_t OFF_RED = (3 + (SAVE_LDS ? 2 : 0) + (SAVEV_LDS ? 1 : 0) + (SAVEF_LDS ? 1 : 0)) * A3;
     // per-wave copies of block-uniform scalars that are touched once per move (counters, the move's saved energies, the slot's
     // constants): kept in LDS instead of ~40 scalar registers that the hot loops would otherwise spill and reload
     static constexpr int UST_PER_WAVE = 32;
@@ -109,7 +109,8 @@ struct Cfg {
     static constexpr size_t OFF_RHO = LIST_LDS ? OFF_NBR + pad8((size_t)MAXNB * NLIST * sizeof(IdxT)) : OFF_NBR; // EAM densities
     static constexpr size_t LDS_BYTES = OFF_RHO + (POT ? (size_t)NMAX * sizeof(double) : 0);
     // per-slot global spill when the saved copies do not fit in LDS: sav, savv, x0 (9 NMAX doubles) + images + wrap counts
-    static constexpr size_t AUX_DOUBLES = SAVE_LDS ? (SAVEV_LDS ? 0 : (size_t)3 * NMAX) : (size_t)9 * NMAX + ((size_t)3 * NMAX * 3 + 7) / 8;
+    static constexpr size_t AUX_SAVES = SAVE_LDS ? (SAVEV_LDS ? 0 : (size_t)3 * NMAX) : (size_t)9 * NMAX + ((size_t)3 * NMAX * 3 + 7) / 8;
+    static constexpr size_t AUX_DOUBLES = AUX_SAVES + (SAVEF_LDS ? 0 : (size_t)3 * NMAX); // ... + the saved forces
     static constexpr size_t NBR_G_ELEMS = LIST_LDS ? 0 : (size_t)MAXNB * NMAX; // per-slot global list
     // Lists that live in HBM/L2 are stored in chunks of CH consecutive neighbours of one atom ([chunk][atom][CH]) so that one
     // 8-byte load brings four indices: the dependent L2 round trip per neighbour was the cost there.  LDS lists stay [slot][atom].
@@ -151,7 +152,8 @@ struct Replica {
     typename ArrSel<C::SAVE_LDS, double, C::OFF_SAV + 2 * A1>::type sz;
     typename ArrSel<C::SAVEV_LDS, double, C::OFF_SAVV>::type svx; typename ArrSel<C::SAVEV_LDS, double, C::OFF_SAVV + A1>::type svy;
     typename ArrSel<C::SAVEV_LDS, double, C::OFF_SAVV + 2 * A1>::type svz;
-    LdsArr<double, C::OFF_SAVF> sfx; LdsArr<double, C::OFF_SAVF + A1> sfy; LdsArr<double, C::OFF_SAVF + 2 * A1> sfz; // when C::SAVE_F
+    typename ArrSel<C::SAVEF_LDS, double, C::OFF_SAVF>::type sfx; typename ArrSel<C::SAVEF_LDS, double, C::OFF_SAVF + A1>::type sfy;
+    typename ArrSel<C::SAVEF_LDS, double, C::OFF_SAVF + 2 * A1>::type sfz; // saved forces of the own atoms
     typename ArrSel<C::SAVE_LDS, double, C::OFF_X0>::type x0; typename ArrSel<C::SAVE_LDS, double, C::OFF_X0 + A1>::type y0;
     typename ArrSel<C::SAVE_LDS, double, C::OFF_X0 + 2 * A1>::type z0;
     typename ArrSel<C::SAVE_LDS, short, C::OFF_IMG>::type im;      // LAMMPS image flags
@@ -200,6 +202,10 @@ struct Replica {
         else if constexpr (!C::SAVEV_LDS) {
             double *a = p.aux_g + ((size_t)slot * p.cus + q_) * C::AUX_DOUBLES;
             svx.g = a; svy.g = a + NMAX; svz.g = a + 2 * (size_t)NMAX;
+        }
+        if constexpr (!C::SAVEF_LDS) {
+            double *a = p.aux_g + ((size_t)slot * p.cus + q_) * C::AUX_DOUBLES + C::AUX_SAVES;
+            sfx.g = a; sfy.g = a + NMAX; sfz.g = a + 2 * (size_t)NMAX;
         }
         if constexpr (!C::LIST_LDS) nbr.g = (IdxT *)p.nbr_g + (size_t)slot * C::NBR_G_ELEMS;
         if (p.tape) { tape = p.tape + p.tape_off[slot]; tlen = p.tape_off[slot + 1] - p.tape_off[slot]; }
@@ -295,11 +301,10 @@ struct Replica {
             sx[i] = px[i]; sy[i] = py[i]; sz[i] = pz[i];
             if (with_v) { svx[i] = vx[i]; svy[i] = vy[i]; svz[i] = vz[i]; }
         }
-        if constexpr (C::SAVE_F) { // the forces of the own atoms, if they belong to these positions
-            flags = fresh() ? (flags | F_SAVED_FRESH) : (flags & ~F_SAVED_FRESH);
-            if (fresh())
-                for (int i = a0 + tid; i < a1; i += BLOCK) { sfx[i] = fx[i]; sfy[i] = fy[i]; sfz[i] = fz[i]; }
-        }
+        // the forces of the own atoms, if they belong to these positions
+        flags = fresh() ? (flags | F_SAVED_FRESH) : (flags & ~F_SAVED_FRESH);
+        if (fresh())
+            for (int i = a0 + tid; i < a1; i += BLOCK) { sfx[i] = fx[i]; sfy[i] = fy[i]; sfz[i] = fz[i]; }
     }
     // The reference answers a rejection with scatter_atoms + `run 0`, i.e. it re-evaluates the old configuration.  The result
     // is what was there before the move (the caller puts U, W back); where the forces were saved too they come back as well and
@@ -311,11 +316,10 @@ struct Replica {
             if (with_v) { vx[i] = svx[i]; vy[i] = svy[i]; vz[i] = svz[i]; }
         }
         set_fresh(false);
-        if constexpr (C::SAVE_F)
-            if (flags & F_SAVED_FRESH) {
-                for (int i = a0 + tid; i < a1; i += BLOCK) { fx[i] = sfx[i]; fy[i] = sfy[i]; fz[i] = sfz[i]; }
-                set_fresh(true);
-            }
+        if (flags & F_SAVED_FRESH) {
+            for (int i = a0 + tid; i < a1; i += BLOCK) { fx[i] = sfx[i]; fy[i] = sfy[i]; fz[i] = sfz[i]; }
+            set_fresh(true);
+        }
     }
     __device__ double sum_mv2()
     {
