@@ -20,60 +20,63 @@ from .lattice import LAT, MASS, TIMESTEP, UNITS
 SEED = 256  # remcmc:851 (hard-coded in the reference, not a flag)
 
 
+# The command line of the reference (remcmc:22-86), as a table: (short, long, kind, default, what it is here).
+# kind: 'flag' = store_true, a type = one value, (type, 2) = two values.  Cluster-control flags are accepted and ignored.
+_FLAGS = (
+    ('-v', '--verbose', 'flag', None, 'print progress'),
+    ('-r', '--restart', 'flag', None, 'start from a restart dump'),
+    ('-p', '--parallel', 'flag', None, 'ignored (replicas always run in parallel on the GPU)'),
+    ('-c', '--client', 'flag', None, 'ignored (no dask)'),
+    ('-d', '--distributed', 'flag', None, 'ignored (ranks come from torch.distributed.run)'),
+    ('-is', '--interpolate_states', 'flag', None, 'interpolate the initial volumes along a pressure row, then 1024 NVE steps'),
+    ('-bm', '--bulk_move', 'flag', None, 'position moves displace all atoms at once'),
+    ('-rd', '--restart_dump', int, 128, 'cycles between restart dumps'),
+    ('-rn', '--restart_name', str, 'remcmc_init', 'run name of the dump to restart from'),
+    ('-rs', '--restart_step', int, 1024, 'cycle index of the dump to restart from'),
+    ('-q', '--queue', str, 'jobqueue', 'ignored'),
+    ('-a', '--allocation', str, 'startup', 'ignored'),
+    ('-nn', '--nodes', int, 1, 'ignored'),
+    ('-np', '--procs_per_node', int, 20, 'ignored'),
+    ('-w', '--walltime', int, 72, 'ignored'),
+    ('-m', '--memory', int, 32, 'ignored'),
+    ('-nw', '--workers', int, 20, 'ignored'),
+    ('-nt', '--threads', int, 1, 'ignored'),
+    ('-mt', '--method', str, 'fork', 'ignored'),
+    ('-n', '--name', str, 'remcmc_init', 'run name (prefix of every file)'),
+    ('-e', '--element', str, 'LJ', 'LJ or Al'),
+    ('-ss', '--supercell_size', int, 5, 'fcc cells per box edge'),
+    ('-pn', '--pressure_number', int, 16, 'points of the pressure grid'),
+    ('-pr', '--pressure_range', (float, 2), [1, 8], 'lowest and highest pressure'),
+    ('-tn', '--temperature_number', int, 16, 'points of the temperature grid'),
+    ('-tr', '--temperature_range', (float, 2), [0.25, 2.5], 'lowest and highest temperature'),
+    ('-sc', '--sample_cutoff', int, 0, 'cycles before recording starts'),
+    ('-sn', '--sample_number', int, 1024, 'cycles'),
+    ('-sm', '--sample_mod', int, 128, 'moves per cycle'),
+    ('-pm', '--position_move', float, 0.125, 'probability of a position move'),
+    ('-vm', '--volume_move', float, 0.125, 'probability of a volume move'),
+    ('-ts', '--timesteps', int, 8, 'velocity-Verlet steps of an HMC move'),
+    ('-dx', '--pos_displace', float, 0.03125, 'initial position step (fraction of the lattice parameter)'),
+    ('-dv', '--vol_displace', float, 0.03125, 'initial step in log volume'),
+)
+
+
 def parse_args(argv=None):
-    """the reference's 34 flags, same names, defaults and return order (remcmc:22-100)"""
-    parser = argparse.ArgumentParser()
-    parser.add_argument('-v', '--verbose', help='verbose output mode', action='store_true')
-    parser.add_argument('-r', '--restart', help='restart run mode', action='store_true')
-    parser.add_argument('-p', '--parallel', help='parallel run mode (accepted, ignored)', action='store_true')
-    parser.add_argument('-c', '--client', help='dask client run mode (accepted, ignored)', action='store_true')
-    parser.add_argument('-d', '--distributed', help='distributed run mode (accepted, ignored)', action='store_true')
-    parser.add_argument('-is', '--interpolate_states', help='interpolate initial states', action='store_true')
-    parser.add_argument('-bm', '--bulk_move', help='bulk position monte carlo moves', action='store_true')
-    parser.add_argument('-rd', '--restart_dump', help='restart dump frequency', type=int, default=128)
-    parser.add_argument('-rn', '--restart_name', help='restart dump simulation name', type=str, default='remcmc_init')
-    parser.add_argument('-rs', '--restart_step', help='restart dump start step', type=int, default=1024)
-    parser.add_argument('-q', '--queue', help='job submission queue (ignored)', type=str, default='jobqueue')
-    parser.add_argument('-a', '--allocation', help='job submission allocation (ignored)', type=str, default='startup')
-    parser.add_argument('-nn', '--nodes', help='job node count (ignored)', type=int, default=1)
-    parser.add_argument('-np', '--procs_per_node', help='number of processors per node (ignored)', type=int, default=20)
-    parser.add_argument('-w', '--walltime', help='job walltime (ignored)', type=int, default=72)
-    parser.add_argument('-m', '--memory', help='job memory (ignored)', type=int, default=32)
-    parser.add_argument('-nw', '--workers', help='job worker count (ignored: ranks come from torch.distributed.run)',
-                        type=int, default=20)
-    parser.add_argument('-nt', '--threads', help='threads per worker (ignored)', type=int, default=1)
-    parser.add_argument('-mt', '--method', help='parallelization method (ignored)', type=str, default='fork')
-    parser.add_argument('-n', '--name', help='simulation name', type=str, default='remcmc_init')
-    parser.add_argument('-e', '--element', help='simulation element', type=str, default='LJ')
-    parser.add_argument('-ss', '--supercell_size', help='simulation supercell size', type=int, default=5)
-    parser.add_argument('-pn', '--pressure_number', help='number of pressures', type=int, default=16)
-    parser.add_argument('-pr', '--pressure_range', help='pressure range (low and high)', type=float, nargs=2, default=[1, 8])
-    parser.add_argument('-tn', '--temperature_number', help='number of temperatures', type=int, default=16)
-    parser.add_argument('-tr', '--temperature_range', help='temperature range (low and high)', type=float, nargs=2,
-                        default=[0.25, 2.5])
-    parser.add_argument('-sc', '--sample_cutoff', help='sample recording cutoff', type=int, default=0)
-    parser.add_argument('-sn', '--sample_number', help='number of samples to generate', type=int, default=1024)
-    parser.add_argument('-sm', '--sample_mod', help='sample collection frequency', type=int, default=128)
-    parser.add_argument('-pm', '--position_move', help='position monte carlo move probability', type=float, default=0.125)
-    parser.add_argument('-vm', '--volume_move', help='volume monte carlo move probability', type=float, default=0.125)
-    parser.add_argument('-ts', '--timesteps', help='hamiltonian monte carlo timesteps', type=int, default=8)
-    parser.add_argument('-dx', '--pos_displace', help='position displacement (lattice proportion)', type=float,
-                        default=0.03125)
-    parser.add_argument('-dv', '--vol_displace', help='logarithmic volume displacement (logarithmic volume proportion)',
-                        type=float, default=0.03125)
-    args = parser.parse_args(argv)
-    return (args.verbose, args.restart, args.parallel, args.client, args.distributed,
-            args.interpolate_states, args.bulk_move,
-            args.restart_dump, args.restart_name, args.restart_step,
-            args.queue, args.allocation, args.nodes, args.procs_per_node,
-            args.walltime, args.memory,
-            args.workers, args.threads, args.method,
-            args.name, args.element, args.supercell_size,
-            args.pressure_number, *args.pressure_range,
-            args.temperature_number, *args.temperature_range,
-            args.sample_cutoff, args.sample_number, args.sample_mod,
-            args.position_move, args.volume_move, args.timesteps,
-            args.pos_displace, args.vol_displace)
+    """the reference's 34 flags with its names and defaults; returns the values in the order of remcmc:89-100
+    (two-value ranges flattened)"""
+    ap = argparse.ArgumentParser(description='NPT-HMC + replica-exchange sampler on MI355X (flags of lammps_remcmc.py)')
+    for short, long_, kind, default, text in _FLAGS:
+        if kind == 'flag':
+            ap.add_argument(short, long_, action='store_true', help=text)
+        elif isinstance(kind, tuple):
+            ap.add_argument(short, long_, type=kind[0], nargs=kind[1], default=default, help=text)
+        else:
+            ap.add_argument(short, long_, type=kind, default=default, help=text)
+    ns = ap.parse_args(argv)
+    out = []
+    for _, long_, kind, _, _ in _FLAGS:
+        val = getattr(ns, long_[2:])
+        out.extend(val) if isinstance(kind, tuple) else out.append(val)
+    return tuple(out)
 
 
 def init_constant(P, T, el, i, j):
