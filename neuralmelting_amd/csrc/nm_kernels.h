@@ -940,19 +940,26 @@ struct Replica {
         box_consts();
         const double invL = bc_invL, rc2 = p.rc * p.rc;
         double s[2] = { 0.0, 0.0 };
-        // 2N work items: item w < N is the pair (new position, atom w), item N + w the pair (old position, atom w) with the
-        // opposite sign, so that all threads of the workgroup carry one pair each at N = 256
-        for (int w = tid; w < 2 * N; w += BLOCK) {
-            const int part = w >= N ? 1 : 0, j = w - part * N;
-            const double cx = part ? ox : nx, cy = part ? oy : ny, cz = part ? oz : nz;
-            double dx = cx - px[j], dy = cy - py[j], dz = cz - pz[j];
-            dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
-            const double r2 = dx * dx + dy * dy + dz * dz;
-            const bool in = (j != k) && r2 < rc2;
-            const double r2i = recip(in ? r2 : 1.0), r6i = r2i * r2i * r2i;
-            const double sg = in ? (part ? -1.0 : 1.0) : 0.0;
-            s[0] += sg * (r6i * (4.0 * r6i - 4.0));
-            s[1] += sg * (r6i * (48.0 * r6i - 24.0));
+        // One work item per atom j, carrying BOTH pairs (new position, j) and (old position, j): atom j's coordinates are then
+        // read by one thread only, the thread that owns j in every elementwise phase (j mod BLOCK) and the only one that ever
+        // writes them in iter_pmc, so a trial needs no barrier besides the one inside its block reduction.  (With the old and
+        // the new pair as separate items the old-position item of atom k's own thread lived in another wave whenever
+        // N mod BLOCK != 0 and read px[k] while the accepted position of the previous trial was being written.)  The two
+        // pair evaluations are independent dependency chains and interleave in the pipeline.
+        for (int j = tid; j < N; j += BLOCK) {
+            const double xj = px[j], yj = py[j], zj = pz[j];
+            double ax = nx - xj, ay = ny - yj, az = nz - zj, bx = ox - xj, by = oy - yj, bz = oz - zj;
+            ax -= L * rint(ax * invL); ay -= L * rint(ay * invL); az -= L * rint(az * invL);
+            bx -= L * rint(bx * invL); by -= L * rint(by * invL); bz -= L * rint(bz * invL);
+            const double ra = ax * ax + ay * ay + az * az, rb = bx * bx + by * by + bz * bz;
+            const bool ina = (j != k) && ra < rc2, inb = (j != k) && rb < rc2;
+            const double ia = recip(ina ? ra : 1.0), ib = recip(inb ? rb : 1.0);
+            const double a6 = ia * ia * ia, b6 = ib * ib * ib;
+            const double sa = ina ? 1.0 : 0.0, sb = inb ? -1.0 : 0.0;
+            s[0] += sa * (a6 * (4.0 * a6 - 4.0));
+            s[0] += sb * (b6 * (4.0 * b6 - 4.0));
+            s[1] += sa * (a6 * (48.0 * a6 - 24.0));
+            s[1] += sb * (b6 * (48.0 * b6 - 24.0));
         }
         block_sum<2, NW, NVMAX>(s, red, parity);
         dE = s[0]; dW = s[1];
@@ -977,7 +984,8 @@ struct Replica {
         // produced one trial at a time: all threads prepare them at once (atom k's own position cannot change before its
         // trial) and park them in f[] and the saved-velocity slot, both dead during a position move.  The trial loop is then
         // one block reduction per trial; it needs no other barrier, because the only position a trial changes is written and
-        // later read as a neighbour by the same thread (k mod BLOCK), and nobody else looks at atom k again in this move.
+        // later read as a neighbour by the same thread (k mod BLOCK: delta_single gives each atom's two pairs to its owner),
+        // and nobody else looks at atom k again in this move.
         const bool pre = (tape == nullptr);
         if (pre)
             for (int k = tid; k < N; k += BLOCK) {

@@ -60,9 +60,16 @@ _FLAGS = (
 )
 
 
-def parse_args(argv=None):
-    """the reference's 34 flags with its names and defaults; returns the values in the order of remcmc:89-100
-    (two-value ranges flattened)"""
+# Flags the reference does not have (long form only, defaults keep the reference's behaviour).
+_EXTRA_FLAGS = (
+    ('--revert_rejected_trials', 'flag', None,
+     'iterative position moves (no -bm): undo a rejected single-atom trial.  The reference does not (its `od` is a NumPy view '
+     'of the coordinates it restores from, remcmc:522-545), so every proposal is kept; that is reproduced by default'),
+)
+
+
+def parse_all(argv=None):
+    """(the reference's values in the order of remcmc:89-100, dict of this driver's extra flags)"""
     ap = argparse.ArgumentParser(description='NPT-HMC + replica-exchange sampler on MI355X (flags of lammps_remcmc.py)')
     for short, long_, kind, default, text in _FLAGS:
         if kind == 'flag':
@@ -71,12 +78,20 @@ def parse_args(argv=None):
             ap.add_argument(short, long_, type=kind[0], nargs=kind[1], default=default, help=text)
         else:
             ap.add_argument(short, long_, type=kind, default=default, help=text)
+    for long_, kind, default, text in _EXTRA_FLAGS:
+        ap.add_argument(long_, action='store_true', help=text)
     ns = ap.parse_args(argv)
     out = []
     for _, long_, kind, _, _ in _FLAGS:
         val = getattr(ns, long_[2:])
         out.extend(val) if isinstance(kind, tuple) else out.append(val)
-    return tuple(out)
+    return tuple(out), {long_[2:]: getattr(ns, long_[2:]) for long_, _, _, _ in _EXTRA_FLAGS}
+
+
+def parse_args(argv=None):
+    """the reference's 34 flags with its names and defaults; returns the values in the order of remcmc:89-100
+    (two-value ranges flattened)"""
+    return parse_all(argv)[0]
 
 
 def init_constant(P, T, el, i, j):
@@ -102,7 +117,8 @@ class Run:
         (self.VERBOSE, self.RESTART, _par, _dask, _dist, self.INTSTS, self.BM, self.REFREQ, self.RENAME, self.RESTEP,
          _q, _a, _nn, _ppn, _w, _m, _nw, _nth, _mt, self.NAME, self.EL, self.SZ, self.NP, self.LP, self.HP,
          self.NT, self.LT, self.HT, self.CUTOFF, self.NSMPL, self.MOD, self.PPOS, self.PVOL, self.NSTPS,
-         self.DX, self.DV) = parse_args(argv)
+         self.DX, self.DV), extra = parse_all(argv)
+        self.ITER_REVERT = bool(extra['revert_rejected_trials'])
         self.cwd = os.getcwd() if cwd is None else cwd
         self.rank, self.world, self.device = rank, world, device
         self.NS = self.NP * self.NT
@@ -305,7 +321,7 @@ class Run:
         from .engine import Engine
         kw = dict(slot0=self.k0, nslots=self.nloc) if self.split_rows else dict(row0=self.row0, nrows=self.nrows)
         return Engine(self.natoms, self.P, self.T, element=self.EL, ppos=self.PPOS, pvol=self.PVOL, nstps=self.NSTPS,
-                      bulk=self.BM, seed=SEED, device=self.device, **kw)
+                      bulk=self.BM, seed=SEED, device=self.device, iter_revert=self.ITER_REVERT, **kw)
 
     def replica_exchange(self, step):
         """replica_exchange (remcmc:776-803): on the device when this rank owns whole rows, else all-gather + identical sweep"""
@@ -314,8 +330,8 @@ class Run:
             eng.set_step(step)
             return eng.exchange(count=bool(self.VERBOSE))
         from . import exchange as X
-        import torch
-        info = (self.world, torch.cuda.is_available())
+        import torch.distributed as dist
+        info = (self.world, dist.get_backend() == 'nccl')   # gloo (CPU rehearsals, also on a GPU box) gathers host tensors
         rows = eng.thermo()
         ev = X.allgather(np.stack([rows[:, 1] + rows[:, 2], rows[:, 4]], axis=1), info)          # (E_tot, V): 16 B per slot
         et = np.array([init_constant(self.P, self.T, self.EL, *divmod(k, self.NT))[0] for k in range(self.NS)])
@@ -342,6 +358,9 @@ class Run:
             return self._idle()
         self.engine = self.make_engine()
         eng = self.engine
+        if not self.BM and not self.ITER_REVERT:
+            self.log('note: iterative position moves follow the reference literally: a rejected single-atom trial is counted '
+                     'but not undone (remcmc:522-545); --revert_rejected_trials gives the corrected move')
         self.init_outputs()
         if self.CUTOFF < self.NSMPL:
             self.init_headers()

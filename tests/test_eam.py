@@ -63,13 +63,17 @@ def test_eam_eval_parity(oracle):
 
 
 @pytest.mark.gpu
-def test_eam_block_trace_parity(oracle):
+@pytest.mark.parametrize('cus', [1, 2, 4])
+def test_eam_block_trace_parity(oracle, monkeypatch, cus):
+    """move by move against the oracle with one, two and four workgroups per replica (CfgSmallSC, CfgSmallSCQ2, CfgSmallSCQ4)"""
     import neuralmelting_amd as nm
+    monkeypatch.setenv('NM_CUS_PER_REPLICA', str(cus))
     mod = 24
     P, T = grids(2, 2, pr=(1.0, 8.0), tr=(300.0, 900.0))
     kw = dict(ppos=0.25, pvol=0.25)
     loop = OracleLoop(oracle, 4, P, T, el='Al', **kw)
     e = nm.Engine(256, P, T, element='Al', **kw)
+    assert e.cus_per_replica == cus
     e.set_state(loop.x, loop.v, loop.box, loop.d)
     e.set_trace(True)
     for step in range(2):

@@ -178,16 +178,23 @@ def test_tape_replay_parity(oracle):
     e.close()
 
 
+# every instantiation nm_api.hip's launch_kind can pick: 5^3 / 6^3 -> CfgMid (Q = 1, 2), CfgMidQ4, CfgMidQ8; 8^3 -> CfgLarge (Q = 1, 2)
+LARGE_CELL_CASES = [(sz, q) for sz in (5, 6) for q in (1, 2, 4, 8)] + [(8, 1), (8, 2)]
+
+
 @pytest.mark.parametrize('bulk', [True, False])
-@pytest.mark.parametrize('sz', [5, 6, 8])
-def test_block_parity_large_cells(oracle, sz, bulk):
+@pytest.mark.parametrize('sz,cus', LARGE_CELL_CASES)
+def test_block_parity_large_cells(oracle, monkeypatch, sz, cus, bulk):
     """the HBM-list kernels (5^3: 500 atoms = the reference's run.sh size, a ragged fit for 64-lane waves; 6^3: 864 atoms;
-    8^3: 2048 atoms) against the oracle, bulk and iterative position moves"""
+    8^3: 2048 atoms) against the oracle, bulk and iterative position moves, at every workgroups-per-replica setting the size
+    has an instantiation for"""
+    monkeypatch.setenv('NM_CUS_PER_REPLICA', str(cus))
     mod = 6
     P, T = grids(1, 2)
     kw = dict(bulk=bulk, ppos=0.3, pvol=0.2)
     loop = OracleLoop(oracle, sz, P, T, **kw)
     e = make_engine(loop, sz, P, T, **kw)
+    assert e.cus_per_replica == cus
     e.set_trace(True)
     e.run_block(mod)
     rows = e.thermo()
@@ -196,6 +203,37 @@ def test_block_parity_large_cells(oracle, sz, bulk):
     ro = loop.rows()
     np.testing.assert_allclose(rows[:, :8], ro[:, :8], rtol=RTOL)
     np.testing.assert_array_equal(rows[:, 8:], ro[:, 8:])
+    x, v, box, d = e.get_state()
+    np.testing.assert_allclose(x, loop.x, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(v, loop.v, rtol=0, atol=1e-7)
+    e.close()
+
+
+@pytest.mark.parametrize('nstps', [1, 3])
+@pytest.mark.parametrize('sz,cus', LARGE_CELL_CASES)
+def test_short_trajectories_parity_large_cells(oracle, monkeypatch, sz, cus, nstps):
+    """the integrator hand-over of the HBM-list kernels: HMC-heavy blocks with one- and three-step trajectories (first kick
+    outside the pair loop, fused middle steps, last evaluation carrying the kinetic energy) at every workgroups-per-replica
+    setting, two blocks so that the second starts from velocities and step sizes the first one left"""
+    monkeypatch.setenv('NM_CUS_PER_REPLICA', str(cus))
+    mod = 5
+    P, T = grids(1, 2)
+    kw = dict(bulk=True, ppos=0.1, pvol=0.1, nstps=nstps)
+    loop = OracleLoop(oracle, sz, P, T, **kw)
+    e = make_engine(loop, sz, P, T, **kw)
+    assert e.cus_per_replica == cus
+    for step in range(2):
+        e.set_step(step)
+        e.run_block(mod)
+        loop.run_block(mod, step)
+        rows, ref = e.thermo(), loop.rows()
+        np.testing.assert_array_equal(rows[:, 8:14], ref[:, 8:14])
+        np.testing.assert_allclose(rows[:, :5], ref[:, :5], rtol=RTOL)
+        x, v, box, d = e.get_state()
+        np.testing.assert_allclose(x, loop.x, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(v, loop.v, rtol=0, atol=1e-7)
+        e.adapt()
+        loop.adapt()
     e.close()
 
 

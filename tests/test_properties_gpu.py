@@ -189,18 +189,18 @@ def test_long_run_statistics_agree_with_the_oracle(oracle):
         lp.exchange(step)
     e.close()
     g, o = np.array(g_rows)[burn:], np.array(o_rows)[burn:]
-    assert same >= 2
+    assert same >= 10, same                                 # identical counters for the first cycles
     n = g.shape[0]
     for col, name in ((1, 'pe'), (4, 'vol')):
         # slot statistics mix the replicas that visit the slot: compare slot means against the pooled scatter
         dm = g[:, :, col].mean(0) - o[:, :, col].mean(0)
         se = np.sqrt((g[:, :, col].var(0, ddof=1) + o[:, :, col].var(0, ddof=1)) / n)
         z = np.abs(dm) / np.maximum(se, 1e-12)
-        assert np.median(z) < 2.0 and (z < 8.0).all(), (name, np.sort(z)[-4:])
+        assert np.median(z) < 1.5 and (z < 5.0).all(), (name, np.sort(z)[-4:])
         assert abs(dm.mean()) < 4.0 * np.sqrt((se ** 2).mean() / 64) + 1e-9, (name, dm.mean())
     # acceptance ratios (columns 14-16) averaged over the run and the adapted step sizes (5-7) at its end
     assert np.abs(g[:, :, 14:17].mean(0) - o[:, :, 14:17].mean(0)).max() < 0.2
     assert np.abs(g[:, :, 14:17].mean((0, 1)) - o[:, :, 14:17].mean((0, 1))).max() < 0.03
     ratio = g[-1, :, 5:8] / o[-1, :, 5:8]
-    assert (ratio > 1 / 2.5).all() and (ratio < 2.5).all()
+    assert (ratio > 1 / 2.0).all() and (ratio < 2.0).all()
     assert abs(np.log(ratio).mean()) < 0.15
