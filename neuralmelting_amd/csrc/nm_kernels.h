@@ -18,6 +18,9 @@ namespace nm {
 #ifndef NM_PAIR_W
 #define NM_PAIR_W 2 // listed neighbours a thread works on at once (pair_vec)
 #endif
+#ifndef NM_PIPE_W
+#define NM_PIPE_W 2 // neighbours per step of the software-pipelined pair loop over LDS lists (2 or 4)
+#endif
 constexpr int NVMAX = 16; // widest block reduction (the 16 raw moments of hmc_velocities)
 
 // Diagnostic build only (-DNM_PROF, never the shipped library): shader-clock stamps per section, summed by lane 0
@@ -33,8 +36,11 @@ constexpr int NVMAX = 16; // widest block reduction (the 16 raw moments of hmc_v
 #ifdef NM_EXPERIMENT
 #define TL_EVALS 512
 #define TLINE(k) do { if (tl && tl_n < TL_EVALS && (tid & 63) == 0) tl[((size_t)(q * NW + (tid >> 6)) * TL_EVALS + tl_n) * 8 + (k)] = wall_clock64(); } while (0)
+// the same for the hand-over that follows evaluation tl_n - 1
+#define TLINE_PREV(k) do { if (tl && tl_n > 0 && tl_n <= TL_EVALS && (tid & 63) == 0) tl[((size_t)(q * NW + (tid >> 6)) * TL_EVALS + tl_n - 1) * 8 + (k)] = wall_clock64(); } while (0)
 #else
 #define TLINE(k) do { } while (0)
+#define TLINE_PREV(k) do { } while (0)
 #endif
 #ifdef NM_PROF
 #define NM_PROF_SLOTS 16
@@ -426,14 +432,16 @@ struct Replica {
     }
 
     // W listed neighbours at once, written stage by stage so that W independent dependency chains interleave (fp64 results
-    // are not available to the next instruction of the same chain for several cycles).
+    // are not available to the next instruction of the same chain for several cycles).  Coordinates of the neighbours are
+    // already in registers (xj, yj, zj); a masked entry holds atom i itself (r2 = 0: finite, multiplied away).
     template <bool WANT_E, int W>
-    __device__ __forceinline__ void pair_vec(const int (&j)[W], const bool (&ok)[W], double xi, double yi, double zi, double invL,
-                                             double rc2, double &ax, double &ay, double &az, double &e, double &w, double &np)
+    __device__ __forceinline__ void pair_pre(const double *xj, const double *yj, const double *zj, const bool *ok, double xi, double yi,
+                                             double zi, double invL, double rc2, double &ax, double &ay, double &az, double &e, double &w,
+                                             double &np)
     {
         double dx[W], dy[W], dz[W], r2[W], y[W], t[W], fp[W];
 #pragma unroll
-        for (int q = 0; q < W; ++q) { dx[q] = xi - px[j[q]]; dy[q] = yi - py[j[q]]; dz[q] = zi - pz[j[q]]; }
+        for (int q = 0; q < W; ++q) { dx[q] = xi - xj[q]; dy[q] = yi - yj[q]; dz[q] = zi - zj[q]; }
 #pragma unroll
         for (int q = 0; q < W; ++q) { dx[q] -= L * rint(dx[q] * invL); dy[q] -= L * rint(dy[q] * invL); dz[q] -= L * rint(dz[q] * invL); }
         double msk[W];
@@ -470,6 +478,42 @@ struct Replica {
             if (WANT_E) w += r2[q] * fp[q];
         }
     }
+    // the same with the gathers from LDS in front (lists that live in HBM/L2: their index loads are what is prefetched there)
+    template <bool WANT_E, int W>
+    __device__ __forceinline__ void pair_vec(const int (&j)[W], const bool (&ok)[W], double xi, double yi, double zi, double invL,
+                                             double rc2, double &ax, double &ay, double &az, double &e, double &w, double &np)
+    {
+        double xj[W], yj[W], zj[W];
+#pragma unroll
+        for (int q = 0; q < W; ++q) { xj[q] = px[j[q]]; yj[q] = py[j[q]]; zj[q] = pz[j[q]]; }
+        pair_pre<WANT_E, W>(xj, yj, zj, ok, xi, yi, zi, invL, rc2, ax, ay, az, e, w, np);
+    }
+
+    // PIPE_W consecutive neighbours of one thread, gathered from LDS ahead of the arithmetic (LDS lists).  Two per step with two
+    // waves on a SIMD; four when a wave has its SIMD to itself (256-thread workgroups: four dependency chains keep the fp64 pipe
+    // busy where two leave bubbles behind v_rcp_f64 and the compare -> mask hazards).
+    static constexpr int PIPE_W = NM_PIPE_W;
+    struct Pack { double x[PIPE_W], y[PIPE_W], z[PIPE_W]; };
+    // entries e .. e+PIPE_W-1 of list word wd = neighbours k .. of this thread; an entry at or beyond `mine` reads atom `self`
+    // instead (in bounds, multiplied away later)
+    __device__ __forceinline__ void gather_pack(Pack &b, unsigned long long wd, int e, int k, int mine, int self) const
+    {
+        constexpr int BITS = 8 * (int)sizeof(IdxT);
+#pragma unroll
+        for (int t = 0; t < PIPE_W; ++t) {
+            const int j = (k + t) < mine ? (int)((wd >> (BITS * (e + t))) & ((1ull << BITS) - 1ull)) : self;
+            b.x[t] = px[j]; b.y[t] = py[j]; b.z[t] = pz[j];
+        }
+    }
+    template <bool WANT_E>
+    __device__ __forceinline__ void compute_pack(const Pack &b, int k, int mine, double xi, double yi, double zi, double invL, double rc2,
+                                                 double &ax, double &ay, double &az, double &e, double &w, double &np)
+    {
+        bool ok[PIPE_W];
+#pragma unroll
+        for (int t = 0; t < PIPE_W; ++t) ok[t] = (k + t) < mine;
+        pair_pre<WANT_E, PIPE_W>(b.x, b.y, b.z, ok, xi, yi, zi, invL, rc2, ax, ay, az, e, w, np);
+    }
 
     // fuse (force-only evaluations inside an HMC trajectory): the lane that holds atom i's force integrates it on the spot —
     // both half kicks around this evaluation and the drift, same arithmetic as advance_and_share(two) — publishes the NEW
@@ -487,25 +531,66 @@ struct Replica {
             if (i < a1) {
                 const double xi = px[i], yi = py[i], zi = pz[i];
                 const int c = cnt[i];
+                [[maybe_unused]] double &e_ = e;
                 if constexpr (C::LIST_LDS) {
-                    constexpr int W = NM_PAIR_W, PW = C::PW, BITS = 8 * (int)sizeof(IdxT);
-                    static_assert(PW % W == 0, "");
+                    // Software pipeline over pairs of neighbours.  A thread works on ~10 neighbours per evaluation (80 listed
+                    // neighbours over TPA = 8 threads): issued just in time, every pair of them paid an LDS round trip (index
+                    // -> address -> three bank-conflicted gathers) in front of its ~35-instruction dependent fp64 chains, and the
+                    // loop ran at ~40 % of its VALU bound.  Here the six gathers of the NEXT pair and the list word after the
+                    // current one are in flight while a pair is computed.  Control flow is wave-uniform (ballots); a thread that
+                    // has run out of neighbours gathers its own atom and multiplies the result away.
+                    // The arithmetic is written out on both sides of "is there another pair" instead of skipping the gathers with
+                    // a branch: where two such paths meet the compiler must assume the fewer outstanding loads, and its s_waitcnt
+                    // in front of the pair loaded a step earlier then also waits for the gathers just issued.  For the same
+                    // reason the look-ahead list word is loaded unconditionally (index clamped), not under a branch.
+                    constexpr int PW = C::PW, NWORDS = MAXNB / (PW * TPA);
+                    static_assert(PW == 8 || PW == 4, "");
                     const unsigned long long *nb64 = (const unsigned long long *)nbr.ptr();
                     const int mine = (c - sub + TPA - 1) / TPA; // neighbours of atom i that this thread handles: slots sub, sub+TPA, ...
-                    for (int k0 = 0; k0 < mine; k0 += PW) {     // one conflict-free 8-byte read = PW of them
-                        const unsigned long long wd = nb64[((size_t)(k0 >> C::LOG2PW) * C::NLIST + lrow(i)) * TPA + sub];
-#pragma unroll
-                        for (int e0 = 0; e0 < PW; e0 += W) {
-                            if (k0 + e0 < mine) {
-                                int jj[W];
-                                bool ok[W];
-#pragma unroll
-                                for (int q = 0; q < W; ++q) {
-                                    ok[q] = (k0 + e0 + q) < mine;
-                                    jj[q] = ok[q] ? (int)((wd >> (BITS * (e0 + q))) & ((1ull << BITS) - 1ull)) : i; // a masked lane looks at itself: finite, ignored
-                                }
-                                pair_vec<WANT_E, W>(jj, ok, xi, yi, zi, invL, rc2, ax, ay, az, e, w, np);
-                            }
+                    const size_t wbase = (size_t)lrow(i) * TPA + sub, wstride = (size_t)C::NLIST * TPA;
+                    unsigned long long wd = nb64[wbase], wn = nb64[wbase + (NWORDS > 1 ? wstride : 0)];
+                    int wi = 1;
+                    constexpr int PK = PIPE_W, SPW = PW / PK; // steps per list word
+                    static_assert(PW % PK == 0, "");
+                    Pack A, B;
+                    gather_pack(A, wd, 0, 0, mine, i);
+                    // computes `cur` (neighbours k ...) while the gathers of `nxt` (entries e ... of word wd: neighbours k + PK ...)
+                    // fly; false when the wave has nothing beyond `cur`
+                    auto step = [&](const Pack &cur, Pack &nxt, int k, int e) -> bool {
+                        if (__ballot(k + PK < mine) == 0ull) {
+                            compute_pack<WANT_E>(cur, k, mine, xi, yi, zi, invL, rc2, ax, ay, az, e_, w, np);
+                            asm volatile("; last pack of the wave"); // (two different markers: the optimiser would otherwise fold
+                            return false;                             //  the two copies of the arithmetic back into one block)
+                        }
+                        gather_pack(nxt, wd, e, k + PK, mine, i);
+                        __builtin_amdgcn_sched_barrier(0); // the gathers stay in front of the arithmetic that hides them
+                        compute_pack<WANT_E>(cur, k, mine, xi, yi, zi, invL, rc2, ax, ay, az, e_, w, np);
+                        asm volatile("; next pack in flight");
+                        return true;
+                    };
+                    auto next_word = [&]() {
+                        wd = wn;
+                        wi = wi + 1 < NWORDS ? wi + 1 : NWORDS - 1;
+                        wn = nb64[wbase + (size_t)wi * wstride];
+                    };
+                    for (int k = 0;; k += 2 * PW) { // two list words per trip when a word is a single step, else one
+                        if constexpr (SPW == 4) {       // 8 entries, 2 per step
+                            if (!step(A, B, k, 2)) break;
+                            if (!step(B, A, k + 2, 4)) break;
+                            if (!step(A, B, k + 4, 6)) break;
+                            next_word();
+                            if (!step(B, A, k + 6, 0)) break;
+                            k -= PW;
+                        } else if constexpr (SPW == 2) { // 8 entries, 4 per step, or 4 entries, 2 per step
+                            if (!step(A, B, k, PK)) break;
+                            next_word();
+                            if (!step(B, A, k + PK, 0)) break;
+                            k -= PW;
+                        } else {                          // 4 entries, 4 per step: two words per trip keep A / B roles fixed
+                            next_word();
+                            if (!step(A, B, k, 0)) break;
+                            next_word();
+                            if (!step(B, A, k + PK, 0)) break;
                         }
                     }
                 } else {
@@ -598,7 +683,8 @@ struct Replica {
         w.y = w.x ^ mg;
         // hipcc adds no wait states for an asm statement: a VMEM store of more than 8 bytes needs one before its data
         // registers may be overwritten (gfx9 hazard), hence the s_nop inside the string
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(g), "v"(w) : "memory");
+        if (NM_DBG(32)) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(g), "v"(w) : "memory"); // experiment: line stays in the XCD's L2
+        else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(g), "v"(w) : "memory");
     }
     // up to three granules per call, issued back to back and waited for once; `poisoned` is set when a granule carries the
     // publisher's overflow mark
@@ -778,7 +864,9 @@ struct Replica {
             ++gen;
         }
         set_fresh(false);
+        TLINE_PREV(6);
         const int fl = block_any3<NW, NVMAX>(timeout != 0, poisoned != 0, c.bad != 0, red, parity);
+        TLINE_PREV(7);
         if (fl & 1) status |= ST_SYNC_TIMEOUT;
         if (fl & 2) status |= ST_LIST_OVERFLOW;
         return (fl & 4) != 0;

@@ -38,8 +38,23 @@ print('  pair done -> granules read (per wave)  median %7.0f  max %7.0f' % (
 print('  last pair done -> last exchange done   %7.0f' % np.median(np.array([np.max(t[:, :, k, 4]) - np.max(t[:, :, k, 3]) for k in ev]) * 10.0))
 print('  exchange done -> next entry (kick etc) %7.0f' % np.median(np.array([np.min(t[:, :, k + 1, 0]) - np.max(t[:, :, k, 4]) for k in ev]) * 10.0))
 print('  entry -> next entry                    %7.0f' % np.median(np.array([np.min(t[:, :, k + 1, 0]) - np.min(t[:, :, k, 0]) for k in ev]) * 10.0))
+print('  hand-over: last pair done -> granules in (per wave) median %7.0f max %7.0f ; -> past its barrier %7.0f' % (
+    np.median(np.array([np.median(t[:, :, k, 6]) - np.max(t[:, :, k, 3]) for k in ev]) * 10.0),
+    np.median(np.array([np.max(t[:, :, k, 6]) - np.max(t[:, :, k, 3]) for k in ev]) * 10.0),
+    np.median(np.array([np.max(t[:, :, k, 7]) - np.max(t[:, :, k, 3]) for k in ev]) * 10.0)))
+print('  barrier after the pair loop: last pair done -> last wave past it %7.0f' % np.median(np.array([np.max(t[:, :, k, 4]) - np.max(t[:, :, k, 3]) for k in ev]) * 10.0))
+print('  hand-over barrier -> next entry %7.0f' % np.median(np.array([np.min(t[:, :, k + 1, 0]) - np.max(t[:, :, k, 7]) for k in ev]) * 10.0))
 wg_done = np.array([[np.max(t[q, :, k, 3]) for q in range(Q)] for k in ev])
 print('  skew between workgroups at pair-loop end (max-min) %7.0f' % np.median((wg_done.max(1) - wg_done.min(1)) * 10.0))
 flat = buf.reshape(-1)
 print('shader clock held during the block: %.0f MHz' % (float(flat[-2]) / float(flat[-1]) * 100.0))
 e.close()
+# per wave of workgroup q: medians of the stamps relative to the cluster's last pair-loop end
+e_ = list(ev)
+last3 = np.max(t[:, :, e_, 3], axis=(0, 1))
+for q in range(Q):
+    print('wg %d  wave: pair-end  barrierA  granules-in  barrierB  next-entry  (ns after the last pair-loop end of the cluster)' % q)
+    for w in range(8):
+        vals = [np.median((t[q, w, e_, k] - last3) * 10.0) for k in (3, 4, 6, 7)]
+        nxt = np.median((t[q, w, [k + 1 for k in e_], 0] - last3) * 10.0)
+        print('      %d   %7.0f %7.0f %7.0f %7.0f %7.0f' % (w, vals[0], vals[1], vals[2], vals[3], nxt))
