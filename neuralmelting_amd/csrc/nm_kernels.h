@@ -18,6 +18,9 @@ namespace nm {
 #ifndef NM_PAIR_W
 #define NM_PAIR_W 2 // listed neighbours a thread works on at once (pair_vec)
 #endif
+#ifndef NM_PIPELINED
+#define NM_PIPELINED 0 // 1: software-pipelined pair loop over LDS lists (gathers of the next pack in flight); measured equal within
+#endif                 // noise at two waves per SIMD (the other wave fills the stalls) at a higher register cost
 #ifndef NM_PIPE_W
 #define NM_PIPE_W 2 // neighbours per step of the software-pipelined pair loop over LDS lists (2 or 4)
 #endif
@@ -135,6 +138,91 @@ struct Cfg {
     static constexpr size_t XG_PART = (size_t)3 * NMAX, XG_RHO = (size_t)3 * NMAX + 4 * QMAX; // granule indices
     static constexpr size_t XBUF_DOUBLES = 2 * XBUF_GRANULES;                    // one exchange buffer (there are two per slot)
 };
+
+// velocity all create / zero linear / zero angular (see Replica::hmc_velocities' comment below for the algebra).  A function of its
+// own, NOT inlined: it runs once per HMC move, and inlined its registers (sixteen running moments, Philox, log / sin / cos) were
+// live-range neighbours of everything the trajectory loop keeps, which the allocator then spilled into that loop.  All state it
+// touches is in LDS at constant offsets; scalars come and go by value.  Returns the new parity of the reduction buffer.
+template <class C>
+__device__ __attribute__((noinline)) int velocity_create(double t, uint32_t tag, double L, int N, int gslot, int parity, double mass,
+                                                         double mvv2e, double kB, uint32_t seed, uint32_t step, short *im_g)
+{
+    constexpr int BLOCK = C::BLOCK, NW = C::NW;
+    constexpr size_t A1 = (size_t)C::NMAX * sizeof(double);
+    const int tid = threadIdx.x;
+    LdsArr<double, C::OFF_POS> px; LdsArr<double, C::OFF_POS + A1> py; LdsArr<double, C::OFF_POS + 2 * A1> pz;
+    LdsArr<double, C::OFF_VEL> vx; LdsArr<double, C::OFF_VEL + A1> vy; LdsArr<double, C::OFF_VEL + 2 * A1> vz;
+    LdsArr<double, C::OFF_RED> red;
+    typename ArrSel<C::SAVE_LDS, short, C::OFF_IMG>::type im; // LAMMPS image flags: LDS, or the per-workgroup global spill
+    if constexpr (!C::SAVE_LDS) {
+        const unsigned long long b = (unsigned long long)(uintptr_t)im_g;
+        im.g = (short *)(uintptr_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                                    (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b)); // (the builtin returns int)
+    }
+    N = __builtin_amdgcn_readfirstlane(N); gslot = __builtin_amdgcn_readfirstlane(gslot); parity = __builtin_amdgcn_readfirstlane(parity);
+    tag = __builtin_amdgcn_readfirstlane(tag); seed = __builtin_amdgcn_readfirstlane(seed); step = __builtin_amdgcn_readfirstlane(step);
+    t = uniform(t); L = uniform(L); mass = uniform(mass); mvv2e = uniform(mvv2e); kB = uniform(kB);
+    const double twopi = 6.283185307179586476925286766559;
+    const double m = mass, fac = 1.0 / sqrt(m), mt = m * N;
+    for (int w = tid; w < 2 * N; w += BLOCK) {
+        const int part = w >= N ? 1 : 0, i = w - part * N;
+        uint32_t o[4];
+        philox4x32_10((uint32_t)i, part ? S_VEL_B : S_VEL_A, tag, step, seed, (uint32_t)gslot, o);
+        const double u1 = u01(o[0], o[1]), u2 = u01(o[2], o[3]);
+        const double r = sqrt(-2.0 * log(1.0 - u1));
+        if (part) vz[i] = r * cos(twopi * u2) * fac;
+        else { vx[i] = r * cos(twopi * u2) * fac; vy[i] = r * sin(twopi * u2) * fac; }
+    }
+    __syncthreads();
+    double a[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = 0.0;
+    for (int i = tid; i < N; i += BLOCK) {
+        const double ax = vx[i], ay = vy[i], az = vz[i];
+        const double X = px[i] + im[3 * i] * L, Y = py[i] + im[3 * i + 1] * L, Z = pz[i] + im[3 * i + 2] * L;
+        a[0] += m * ax; a[1] += m * ay; a[2] += m * az;
+        a[3] += m * X; a[4] += m * Y; a[5] += m * Z;
+        a[6] += m * (ax * ax + ay * ay + az * az);
+        a[7] += m * (Y * az - Z * ay);
+        a[8] += m * (Z * ax - X * az);
+        a[9] += m * (X * ay - Y * ax);
+        a[10] += m * (Y * Y + Z * Z);
+        a[11] += m * (X * X + Z * Z);
+        a[12] += m * (X * X + Y * Y);
+        a[13] -= m * X * Y;
+        a[14] -= m * Y * Z;
+        a[15] -= m * X * Z;
+    }
+    block_sum<16, NW, NVMAX>(a, red, parity);
+    const double c0 = a[0] / mt, c1 = a[1] / mt, c2 = a[2] / mt;   // COM velocity
+    const double cx = a[3] / mt, cy = a[4] / mt, cz = a[5] / mt;   // centre of mass (unwrapped)
+    const double dof = 3.0 * N - 3.0;
+    const double s2 = a[6] - mt * (c0 * c0 + c1 * c1 + c2 * c2);
+    const double tcur = s2 * mvv2e / (dof * kB);
+    const double sc = sqrt(t / tcur);
+    const double L0_ = sc * (a[7] - mt * (cy * c2 - cz * c1));
+    const double L1_ = sc * (a[8] - mt * (cz * c0 - cx * c2));
+    const double L2_ = sc * (a[9] - mt * (cx * c1 - cy * c0));
+    const double I00 = a[10] - mt * (cy * cy + cz * cz), I11 = a[11] - mt * (cx * cx + cz * cz), I22 = a[12] - mt * (cx * cx + cy * cy);
+    const double I01 = a[13] + mt * cx * cy, I12 = a[14] + mt * cy * cz, I02 = a[15] + mt * cx * cz;
+    const double det = I00 * I11 * I22 + I01 * I12 * I02 + I02 * I01 * I12 - I00 * I12 * I12 - I01 * I01 * I22 - I02 * I11 * I02;
+    double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+    if (det > 0.0) {
+        const double i00 = I11 * I22 - I12 * I12, i01 = -(I01 * I22 - I02 * I12), i02 = I01 * I12 - I02 * I11;
+        const double i10 = -(I01 * I22 - I12 * I02), i11 = I00 * I22 - I02 * I02, i12 = -(I00 * I12 - I02 * I01);
+        const double i20 = I01 * I12 - I11 * I02, i21 = -(I00 * I12 - I01 * I02), i22 = I00 * I11 - I01 * I01;
+        w0 = (i00 * L0_ + i01 * L1_ + i02 * L2_) / det;
+        w1 = (i10 * L0_ + i11 * L1_ + i12 * L2_) / det;
+        w2 = (i20 * L0_ + i21 * L1_ + i22 * L2_) / det;
+    }
+    for (int i = tid; i < N; i += BLOCK) {
+        const double dx = px[i] + im[3 * i] * L - cx, dy = py[i] + im[3 * i + 1] * L - cy, dz = pz[i] + im[3 * i + 2] * L - cz;
+        vx[i] = (vx[i] - c0) * sc - (w1 * dz - w2 * dy);
+        vy[i] = (vy[i] - c1) * sc - (w2 * dx - w0 * dz);
+        vz[i] = (vz[i] - c2) * sc - (w0 * dy - w1 * dx);
+    }
+    return parity;
+}
 
 template <class C>
 struct Replica {
@@ -532,7 +620,28 @@ struct Replica {
                 const double xi = px[i], yi = py[i], zi = pz[i];
                 const int c = cnt[i];
                 [[maybe_unused]] double &e_ = e;
-                if constexpr (C::LIST_LDS) {
+                if constexpr (C::LIST_LDS && !NM_PIPELINED) {
+                    constexpr int W = NM_PAIR_W, PW = C::PW, BITS = 8 * (int)sizeof(IdxT);
+                    static_assert(PW % W == 0, "");
+                    const unsigned long long *nb64 = (const unsigned long long *)nbr.ptr();
+                    const int mine = (c - sub + TPA - 1) / TPA; // neighbours of atom i that this thread handles: slots sub, sub+TPA, ...
+                    for (int k0 = 0; k0 < mine; k0 += PW) {     // one conflict-free 8-byte read = PW of them
+                        const unsigned long long wd = nb64[((size_t)(k0 >> C::LOG2PW) * C::NLIST + lrow(i)) * TPA + sub];
+#pragma unroll
+                        for (int e0 = 0; e0 < PW; e0 += W) {
+                            if (k0 + e0 < mine) {
+                                int jj[W];
+                                bool ok[W];
+#pragma unroll
+                                for (int q = 0; q < W; ++q) {
+                                    ok[q] = (k0 + e0 + q) < mine;
+                                    jj[q] = ok[q] ? (int)((wd >> (BITS * (e0 + q))) & ((1ull << BITS) - 1ull)) : i; // a masked lane looks at itself: finite, ignored
+                                }
+                                pair_vec<WANT_E, W>(jj, ok, xi, yi, zi, invL, rc2, ax, ay, az, e, w, np);
+                            }
+                        }
+                    }
+                } else if constexpr (C::LIST_LDS) {
                     // Software pipeline over pairs of neighbours.  A thread works on ~10 neighbours per evaluation (80 listed
                     // neighbours over TPA = 8 threads): issued just in time, every pair of them paid an LDS round trip (index
                     // -> address -> three bank-conflicted gathers) in front of its ~35-instruction dependent fp64 chains, and the
@@ -824,8 +933,8 @@ struct Replica {
     // Every position is tested against the list-validity bound by the thread that writes it, so the one block-wide OR at the
     // end is the barrier that publishes the positions AND the rebuild decision: the evaluation that follows starts at once.
     // Requires that no thread of the workgroup still reads positions (the caller's evaluation ended with a barrier).
-    // mode 1: one half kick + drift; 2: two half kicks + drift; 3: the pair loop did it already (fuse): f[] holds the new positions
-    // of the own atoms and they are published.
+    // mode 1: one half kick + drift; 3: the pair loop did it already (eval_force): f[] holds the new positions of the own atoms
+    // and they are published.
     __device__ bool advance_and_share(int mode, double dtfm, double h)
     {
         int timeout = 0, poisoned = 0;
@@ -835,8 +944,7 @@ struct Replica {
         for (int i = a0 + tid; i < a1; i += BLOCK) {
             const double gx = fx[i], gy = fy[i], gz = fz[i];
             if (mode == 3) { px[i] = gx; py[i] = gy; pz[i] = gz; continue; }
-            double ux = __builtin_fma(dtfm, gx, vx[i]), uy = __builtin_fma(dtfm, gy, vy[i]), uz = __builtin_fma(dtfm, gz, vz[i]);
-            if (mode == 2) { ux = __builtin_fma(dtfm, gx, ux); uy = __builtin_fma(dtfm, gy, uy); uz = __builtin_fma(dtfm, gz, uz); }
+            const double ux = __builtin_fma(dtfm, gx, vx[i]), uy = __builtin_fma(dtfm, gy, vy[i]), uz = __builtin_fma(dtfm, gz, vz[i]);
             vx[i] = ux; vy[i] = uy; vz[i] = uz;
             const double nx = __builtin_fma(h, ux, px[i]), ny = __builtin_fma(h, uy, py[i]), nz = __builtin_fma(h, uz, pz[i]);
             px[i] = nx; py[i] = ny; pz[i] = nz;
@@ -878,7 +986,7 @@ struct Replica {
     // have_need: the caller already holds the rebuild decision for the current positions (advance_and_share) and the barrier
     // that goes with it.  An energy evaluation leaves this workgroup's partial sums in psum[]; finish_sums() makes U, W of them
     // (across the cluster, together with one more partial sum of the caller: the kinetic energy at the end of a trajectory).
-    __device__ void eval(bool want_e, bool have_need = false, bool pre_need = false, bool fuse = false, double dtfm = 0.0, double h = 0.0)
+    __device__ void eval(bool have_need = false, bool pre_need = false)
     {
         if (status & (ST_SYNC_TIMEOUT | ST_LIST_OVERFLOW)) return; // learnt from the last hand-over: the cluster is leaving
         if (!(L >= 2.0 * p.rc)) { status |= ST_BOX_TOO_SMALL; __syncthreads(); return; } // minimum-image limit
@@ -907,19 +1015,48 @@ struct Replica {
         double eacc = 0.0, wacc = 0.0, nacc = 0.0;
         PROF_BEGIN();
         if (NM_DBG(16)) { }
-        else if constexpr (C::POT == 1) { if (want_e) pair_loop_sc<true>(invL, eacc, wacc, nacc, false, 0.0, 0.0); else pair_loop_sc<false>(invL, eacc, wacc, nacc, fuse, dtfm, h); }
-        else if (want_e) pair_loop<true>(invL, eacc, wacc, nacc, false, 0.0, 0.0);
-        else pair_loop<false>(invL, eacc, wacc, nacc, fuse, dtfm, h);
+        else if constexpr (C::POT == 1) pair_loop_sc<true>(invL, eacc, wacc, nacc, false, 0.0, 0.0);
+        else pair_loop<true>(invL, eacc, wacc, nacc, false, 0.0, 0.0);
         PROF_END(3);
         TLINE(3);
         PROF_BEGIN();
         st_evals += 1.0;
         double s[3] = { eacc, wacc, nacc };
-        if (want_e) block_sum<3, NW, NVMAX>(s, red, parity); // over this workgroup's atoms
-        else __syncthreads();                                 // nobody reads positions any more: they may be advanced
+        block_sum<3, NW, NVMAX>(s, red, parity); // over this workgroup's atoms
         PROF_END(4);
         TLINE(4);
-        if (want_e) { psum[0] = s[0]; psum[1] = s[1]; psum[2] = s[2]; }
+        psum[0] = s[0]; psum[1] = s[1]; psum[2] = s[2];
+        ++tl_n;
+        set_fresh(true);
+    }
+
+    // The force-only evaluation inside an HMC trajectory (fix nve between two `run` boundaries): the rebuild decision for the
+    // current positions came with the hand-over (advance_and_share) together with the barrier that published them.  The pair
+    // loop integrates the own atoms on the spot (both half kicks around this evaluation, the drift) and publishes their new
+    // positions; it ends with the barrier after which positions may be overwritten.  ONE call site (the trajectory loop of the
+    // block kernel), so this and eval() hold one pair loop each.
+    __device__ __forceinline__ void eval_force(bool need, double dtfm, double h)
+    {
+        TLINE(0);
+        TLINE(1);
+        PROF_BEGIN();
+        if (need || !(flags & F_LIST_OK)) rebuild();
+        PROF_END(2);
+        TLINE(2);
+        box_consts();
+        const double invL = bc_invL;
+        double eacc = 0.0, wacc = 0.0, nacc = 0.0;
+        PROF_BEGIN();
+        if (NM_DBG(16)) { }
+        else if constexpr (C::POT == 1) pair_loop_sc<false>(invL, eacc, wacc, nacc, true, dtfm, h);
+        else pair_loop<false>(invL, eacc, wacc, nacc, true, dtfm, h);
+        PROF_END(3);
+        TLINE(3);
+        PROF_BEGIN();
+        st_evals += 1.0;
+        __syncthreads(); // nobody reads positions any more: they may be advanced
+        PROF_END(4);
+        TLINE(4);
         ++tl_n;
         set_fresh(true);
     }
@@ -954,70 +1091,11 @@ struct Replica {
     //   I about the COM            = raw second moments - M (|Xc|^2 1 - Xc Xc^T)   (parallel axis)
     // and one pass that writes v = sc (v - c) - omega x (X - Xc).  The second "zero linear" would subtract the round-off of
     // sum m v' / M (~1e-17 relative); it is left out.  Differences to the four-pass arithmetic are ~1e-15 relative.
-    __device__ void hmc_velocities(double t, uint32_t tag)
+    __device__ __forceinline__ void hmc_velocities(double t, uint32_t tag)
     {
-        const double twopi = 6.283185307179586476925286766559;
-        const double m = p.mass, fac = 1.0 / sqrt(m), mt = m * N;
-        if (!NM_DBG(2)) {
-            for (int w = tid; w < 2 * N; w += BLOCK) {
-                const int part = w >= N ? 1 : 0, i = w - part * N;
-                uint32_t o[4];
-                philox4x32_10((uint32_t)i, part ? S_VEL_B : S_VEL_A, tag, p.step, p.seed, (uint32_t)gslot, o);
-                const double u1 = u01(o[0], o[1]), u2 = u01(o[2], o[3]);
-                const double r = sqrt(-2.0 * log(1.0 - u1));
-                if (part) vz[i] = r * cos(twopi * u2) * fac;
-                else { vx[i] = r * cos(twopi * u2) * fac; vy[i] = r * sin(twopi * u2) * fac; }
-            }
-            __syncthreads();
-        }
-        double a[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = 0.0;
-        for (int i = tid; i < N; i += BLOCK) {
-            const double ax = vx[i], ay = vy[i], az = vz[i];
-            const double X = px[i] + im[3 * i] * L, Y = py[i] + im[3 * i + 1] * L, Z = pz[i] + im[3 * i + 2] * L;
-            a[0] += m * ax; a[1] += m * ay; a[2] += m * az;
-            a[3] += m * X; a[4] += m * Y; a[5] += m * Z;
-            a[6] += m * (ax * ax + ay * ay + az * az);
-            a[7] += m * (Y * az - Z * ay);
-            a[8] += m * (Z * ax - X * az);
-            a[9] += m * (X * ay - Y * ax);
-            a[10] += m * (Y * Y + Z * Z);
-            a[11] += m * (X * X + Z * Z);
-            a[12] += m * (X * X + Y * Y);
-            a[13] -= m * X * Y;
-            a[14] -= m * Y * Z;
-            a[15] -= m * X * Z;
-        }
-        if (NM_DBG(1)) return;
-        block_sum<16, NW, NVMAX>(a, red, parity);
-        const double c0 = a[0] / mt, c1 = a[1] / mt, c2 = a[2] / mt;   // COM velocity
-        const double cx = a[3] / mt, cy = a[4] / mt, cz = a[5] / mt;   // centre of mass (unwrapped)
-        const double dof = 3.0 * N - 3.0;
-        const double s2 = a[6] - mt * (c0 * c0 + c1 * c1 + c2 * c2);
-        const double tcur = s2 * p.mvv2e / (dof * p.kB);
-        const double sc = sqrt(t / tcur);
-        const double L0_ = sc * (a[7] - mt * (cy * c2 - cz * c1));
-        const double L1_ = sc * (a[8] - mt * (cz * c0 - cx * c2));
-        const double L2_ = sc * (a[9] - mt * (cx * c1 - cy * c0));
-        const double I00 = a[10] - mt * (cy * cy + cz * cz), I11 = a[11] - mt * (cx * cx + cz * cz), I22 = a[12] - mt * (cx * cx + cy * cy);
-        const double I01 = a[13] + mt * cx * cy, I12 = a[14] + mt * cy * cz, I02 = a[15] + mt * cx * cz;
-        const double det = I00 * I11 * I22 + I01 * I12 * I02 + I02 * I01 * I12 - I00 * I12 * I12 - I01 * I01 * I22 - I02 * I11 * I02;
-        double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-        if (det > 0.0) {
-            const double i00 = I11 * I22 - I12 * I12, i01 = -(I01 * I22 - I02 * I12), i02 = I01 * I12 - I02 * I11;
-            const double i10 = -(I01 * I22 - I12 * I02), i11 = I00 * I22 - I02 * I02, i12 = -(I00 * I12 - I02 * I01);
-            const double i20 = I01 * I12 - I11 * I02, i21 = -(I00 * I12 - I01 * I02), i22 = I00 * I11 - I01 * I01;
-            w0 = (i00 * L0_ + i01 * L1_ + i02 * L2_) / det;
-            w1 = (i10 * L0_ + i11 * L1_ + i12 * L2_) / det;
-            w2 = (i20 * L0_ + i21 * L1_ + i22 * L2_) / det;
-        }
-        for (int i = tid; i < N; i += BLOCK) {
-            const double dx = px[i] + im[3 * i] * L - cx, dy = py[i] + im[3 * i + 1] * L - cy, dz = pz[i] + im[3 * i + 2] * L - cz;
-            vx[i] = (vx[i] - c0) * sc - (w1 * dz - w2 * dy);
-            vy[i] = (vy[i] - c1) * sc - (w2 * dx - w0 * dz);
-            vz[i] = (vz[i] - c2) * sc - (w0 * dy - w1 * dx);
-        }
+        short *img = nullptr;
+        if constexpr (!C::SAVE_LDS) img = im.g;
+        parity = velocity_create<C>(t, tag, L, N, gslot, parity, p.mass, p.mvv2e, p.kB, p.seed, p.step, img);
     }
 
     // ------------------------------------------------------------------ the moves
@@ -1304,7 +1382,7 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
 // Phases of the per-replica state machine.  The block kernel is written so that eval() — by far the largest
 // piece of code and the only one whose cost matters — has exactly ONE call site; every move is split into the
 // part before its energy/force evaluation and the part after it.
-enum : int { PH_INIT = 0, PH_BULK = 1, PH_VMC = 2, PH_HMC_START = 3, PH_HMC_STEP = 4 };
+enum : int { PH_INIT = 0, PH_BULK = 1, PH_VMC = 2, PH_HMC_START = 3, PH_HMC_STEP = 4 }; // PH_HMC_STEP: the trajectory's last evaluation
 
 // one workgroup = one replica for MOD moves
 template <class C>
@@ -1343,8 +1421,8 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
     const int fatal = ST_BOX_TOO_SMALL | ST_LIST_OVERFLOW | ST_SYNC_TIMEOUT;
 
     // state carried across the evaluation of a move
-    int phase = PH_INIT, m = 0, hstep = 0;
-    bool want_e = true, skip_eval = false;
+    int phase = PH_INIT, m = 0;
+    bool skip_eval = false;
     double &mv2new = R.ust(18); // kinetic-energy sum delivered with the last evaluation of a trajectory
     mv2new = 0.0;
     bool have_need = false, pre_need = false; // rebuild decision delivered with a position hand-over (HMC steps)
@@ -1353,13 +1431,11 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
 
     for (;;) {
         const int st_before = R.status;
-        // a force-only evaluation inside a trajectory integrates and publishes in its pair loop
-        const bool fuse = phase == PH_HMC_STEP && !want_e && !skip_eval;
         if (!skip_eval) {
-            R.eval(want_e, have_need, pre_need, fuse, c_dtfm, c_h);
-            // cluster-wide U, W of an energy evaluation — ONE exchange site.  The evaluation before the last half kick of a
-            // trajectory (the only energy evaluation in phase PH_HMC_STEP) takes the kinetic energy along in the same exchange.
-            if (want_e && !(st_before & fatal) && !(R.status & (ST_BOX_TOO_SMALL | ST_SYNC_TIMEOUT))) {
+            R.eval(have_need, pre_need);
+            // cluster-wide U, W of an energy evaluation — ONE exchange site.  The last evaluation of a trajectory (the only one
+            // in phase PH_HMC_STEP) takes the kinetic energy along in the same exchange.
+            if (!(st_before & fatal) && !(R.status & (ST_BOX_TOO_SMALL | ST_SYNC_TIMEOUT))) {
                 double extra = 0.0;
                 if (phase == PH_HMC_STEP) {
                     for (int i = R.a0 + tid; i < R.a1; i += BLOCK) { // final_integrate of the last step
@@ -1384,7 +1460,6 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
 
         // ---------------- part of the move after its evaluation
         bool move_done = false, acc = false;
-        int share = 0; // 1: half kick + drift, 2: two half kicks + drift, then the position hand-over
         double crit = 0.0, branch = 0.0;
         if (phase == PH_INIT) {
             if (p.eval_only) { // nm_eval: batched lj_energy_force on the resident states
@@ -1418,31 +1493,36 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
             R.save(true);
             U0 = R.U; W0 = R.W;
             c_pe = R.U / et + 0.5 * p.mvv2e * R.sum_mv2() / et; // etot
-            hstep = 0;
-            share = 1;
-            phase = PH_HMC_STEP; want_e = (p.nstps == 1);
-        } else { // PH_HMC_STEP: forces at the new positions are in
-            ++hstep;
-            if (hstep < p.nstps) {
-                share = fuse ? 3 : 2; // final_integrate of this step + initial_integrate of the next
-                want_e = (hstep == p.nstps - 1);
-            } else {
-                const double etotnew = R.U / et + 0.5 * p.mvv2e * mv2new / et; // remcmc:618-622
-                crit = etotnew - c_pe;
-                if (p.md_mode) acc = true; // plain NVE run (init_sample -is, remcmc:421-425): nothing to accept
-                else {
-                    acc = R.metropolis(crit, S_ACC, (uint32_t)m, 0);
-                    if (acc) nah += 1.0;
-                    else { R.restore(true); R.wrap(); R.U = U0; R.W = W0; }
-                }
-                branch = 2.0; move_done = true;
-            }
-        }
-        if (share) { // ONE hand-over site
-            pre_need = R.advance_and_share(share, c_dtfm, c_h);
-            have_need = true;
             PROF_END(5 + prof_phase);
+            // `run NSTPS` (fix nve): initial_integrate of step 1, then the NSTPS - 1 force-only evaluations, each of which
+            // integrates in its pair loop (final_integrate of its step + initial_integrate of the next) and hands the new
+            // positions over.  The NSTPS-th evaluation also wants the energy: it is the generic one at the top of this loop.
+            const double dtfm_ = uniform(c_dtfm), h_ = uniform(c_h);
+            PROF_BEGIN();
+            pre_need = R.advance_and_share(1, dtfm_, h_);
+            PROF_END(9);
+            const int nfo = p.nstps - 1;
+            for (int s = 0; s < nfo; ++s) {
+                if (__builtin_amdgcn_readfirstlane(R.status) & fatal) break;
+                R.eval_force(pre_need, dtfm_, h_);
+                if (__builtin_amdgcn_readfirstlane(R.status) & fatal) break; // own list overflowed: what the pair loop published is poisoned
+                PROF_BEGIN();
+                pre_need = R.advance_and_share(3, dtfm_, h_);
+                PROF_END(9);
+            }
+            have_need = true;
+            phase = PH_HMC_STEP;
             continue;
+        } else { // PH_HMC_STEP: the trajectory is complete, energies at its end are in
+            const double etotnew = R.U / et + 0.5 * p.mvv2e * mv2new / et; // remcmc:618-622
+            crit = etotnew - c_pe;
+            if (p.md_mode) acc = true; // plain NVE run (init_sample -is, remcmc:421-425): nothing to accept
+            else {
+                acc = R.metropolis(crit, S_ACC, (uint32_t)m, 0);
+                if (acc) nah += 1.0;
+                else { R.restore(true); R.wrap(); R.U = U0; R.W = W0; }
+            }
+            branch = 2.0; move_done = true;
         }
         if (move_done) {
             if (p.trace && writer) {
@@ -1474,7 +1554,7 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
                 }
                 R.set_fresh(false);
                 R.wrap();
-                phase = PH_BULK; want_e = true; pending = true;
+                phase = PH_BULK; pending = true;
                 PROF_END(10);
             } else if (roll <= p.ppos) { // iter_position_mc: local energy differences, no full evaluation
                 double c2 = 0.0;
@@ -1498,7 +1578,7 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
                 R.set_fresh(false);
                 R.L = uniform(q6(boxnew)); // change_box ... %f
                 R.wrap();
-                phase = PH_VMC; want_e = true; pending = true;
+                phase = PH_VMC; pending = true;
                 PROF_END(11);
             } else { // hamiltonian_mc, remcmc:598-608
                 if (!p.md_mode) nth += 1.0;
@@ -1507,7 +1587,7 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
                 c_h = uniform(q6(dt)); // timestep %f
                 c_dtfm = 0.5 * c_h * p.ftm2v / p.mass;
                 R.wrap(); // run 0
-                phase = PH_HMC_START; want_e = true; pending = true;
+                phase = PH_HMC_START; pending = true;
                 skip_eval = R.fresh(); // nothing moved since the last evaluation: same U, W, f
                 PROF_END(12);
             }
