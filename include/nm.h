@@ -100,6 +100,15 @@ int nm_adapt(nm_ctx *ctx);
 int nm_exchange(nm_ctx *ctx, int *nswaps);
 /* waits for everything enqueued on the context; reports replicas that left the supported regime */
 int nm_synchronize(nm_ctx *ctx);
+/* status[nslots]: 0, or the NM_ST_* bits that stopped the slot's last block.  A block that ends on an error leaves the slot's
+   x, v, box and thermo scalars as they were when it started (the reference's LAMMPS would have aborted the process). */
+#define NM_ST_LIST_OVERFLOW 1   /* more neighbours within rc + skin than list slots                           */
+#define NM_ST_BOX_TOO_SMALL 2   /* box edge < 2 rc: outside the minimum-image regime                          */
+#define NM_ST_TAPE_EXHAUSTED 4  /* test-only rng tape too short                                               */
+#define NM_ST_NONFINITE 8       /* non-finite energy                                                          */
+#define NM_ST_SYNC_TIMEOUT 16   /* a hand-over between the workgroups of a replica timed out                  */
+#define NM_ST_NOT_RESIDENT 32   /* the launch's workgroups were not resident together; nothing was changed    */
+int nm_get_status(nm_ctx *ctx, int *status);
 
 /* measurement: HIP-event time of the nm_run_block kernel launches since the last reset */
 int nm_timing_reset(nm_ctx *ctx);

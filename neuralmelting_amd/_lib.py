@@ -17,7 +17,7 @@ NM_THERMO_COLS, NM_TRACE_COLS, NM_STATS_COLS = 17, 4, 4
 # every symbol include/nm.h declares (tests check that the library exports all of them)
 SYMBOLS = ('nm_create', 'nm_destroy', 'nm_last_error', 'nm_nslots', 'nm_natoms', 'nm_cus_per_replica', 'nm_get_const',
            'nm_set_state', 'nm_get_state', 'nm_set_thermo', 'nm_set_step', 'nm_run_md', 'nm_run_block', 'nm_get_thermo', 'nm_adapt',
-           'nm_exchange', 'nm_synchronize', 'nm_format_thrm', 'nm_format_traj', 'nm_append_outputs', 'nm_timing_reset', 'nm_timing_get', 'nm_stats_get', 'nm_eval',
+           'nm_exchange', 'nm_synchronize', 'nm_get_status', 'nm_format_thrm', 'nm_format_traj', 'nm_append_outputs', 'nm_timing_reset', 'nm_timing_get', 'nm_stats_get', 'nm_eval',
            'nm_set_rng_tape', 'nm_set_exchange_tape', 'nm_set_trace', 'nm_get_trace', 'nm_get_perm',
            'nm_get_exchange_crit')
 
@@ -67,6 +67,7 @@ def load():
     L.nm_adapt.argtypes = [vp]
     L.nm_exchange.argtypes = [vp, c_int_p]
     L.nm_synchronize.argtypes = [vp]
+    L.nm_get_status.argtypes = [vp, c_int_p]
     L.nm_format_thrm.argtypes = [c_double_p, C.c_char_p, C.c_int]
     L.nm_format_traj.argtypes = [C.c_int, C.c_double, c_double_p, C.c_char_p, C.c_int]
     L.nm_append_outputs.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), c_double_p, c_double_p, c_double_p,

@@ -63,6 +63,7 @@ struct nm_ctx {
     double *d_x, *d_v, *d_box, *d_steps, *d_therm, *d_count, *d_et, *d_pf, *d_tq, *d_stats;
     float *d_ratio;
     int *d_slot2buf, *d_status, *d_nswaps;
+    unsigned int *d_census; // residency census of cluster launches (nm_kernels.h)
     double *d_tape, *d_xtape, *d_trace, *d_xcrit, *d_evalU, *d_evalW, *d_evalF, *d_aux;
     int *d_tape_off;
     void *d_nbr;
@@ -117,6 +118,7 @@ void fill_params(const nm_ctx *c, KParams &p)
     p.nbr_g = c->d_nbr; p.aux_g = c->d_aux;
     p.prof = c->d_prof;
     p.cus = c->cus; p.xbuf = c->d_xbuf; p.launch_id = c->launch_id;
+    p.census = c->cus > 1 ? c->d_census : nullptr; p.census_only = 0;
     p.dbg = 0;
     p.tline = c->d_tline;
     if (const char *e = std::getenv("NM_DBG")) p.dbg = std::atoi(e);
@@ -130,8 +132,22 @@ void fill_params(const nm_ctx *c, KParams &p)
 template <class C>
 hipError_t launch_block(const nm_ctx *c, const KParams &p)
 {
+    if (p.census) { // the arrival counter of this launch's residency census
+        const hipError_t e = hipMemsetAsync(c->d_census, 0, sizeof(unsigned int), c->stream);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(nm_block_kernel<C>, dim3(c->nslots * c->cus), dim3(C::BLOCK), C::LDS_BYTES, c->stream, p);
     return hipGetLastError();
+}
+
+// workgroups of the block kernel one CU admits (LDS, registers), for the configuration launch_kind would pick at q per replica
+template <class C>
+int blocks_per_cu()
+{
+    int n = 0;
+    if (hipFuncSetAttribute((const void *)nm_block_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, nm_block_kernel<C>, C::BLOCK, C::LDS_BYTES) != hipSuccess) return 0;
+    return n;
 }
 
 hipError_t launch_kind(const nm_ctx *c, const KParams &p)
@@ -142,6 +158,17 @@ hipError_t launch_kind(const nm_ctx *c, const KParams &p)
         return c->cus == 8 ? launch_block<CfgSmallQ8>(c, p) : c->cus == 4 ? launch_block<CfgSmallQ4>(c, p) : c->cus == 2 ? launch_block<CfgSmallQ2>(c, p) : launch_block<CfgSmall>(c, p);
     case 1: return c->cus == 8 ? launch_block<CfgMidQ8>(c, p) : c->cus == 4 ? launch_block<CfgMidQ4>(c, p) : launch_block<CfgMid>(c, p);
     default: return launch_block<CfgLarge>(c, p);
+    }
+}
+
+int blocks_per_cu_kind(int kind, int pot, int q)
+{
+    switch (kind) {
+    case 0:
+        if (pot == 1) return q == 4 ? blocks_per_cu<CfgSmallSCQ4>() : q == 2 ? blocks_per_cu<CfgSmallSCQ2>() : blocks_per_cu<CfgSmallSC>();
+        return q == 8 ? blocks_per_cu<CfgSmallQ8>() : q == 4 ? blocks_per_cu<CfgSmallQ4>() : q == 2 ? blocks_per_cu<CfgSmallQ2>() : blocks_per_cu<CfgSmall>();
+    case 1: return q == 8 ? blocks_per_cu<CfgMidQ8>() : q == 4 ? blocks_per_cu<CfgMidQ4>() : blocks_per_cu<CfgMid>();
+    default: return blocks_per_cu<CfgLarge>();
     }
 }
 
@@ -162,14 +189,16 @@ int check_status(nm_ctx *c)
         return fail(c, NM_ERR_HIP, "status readback failed");
     for (int k = 0; k < c->nslots; ++k)
         if (st[k]) {
-            char buf[256];
+            char buf[512];
             std::snprintf(buf, sizeof buf,
-                          "replica slot %d (global %d) left the supported regime:%s%s%s%s%s", k, c->slot0 + k,
+                          "replica slot %d (global %d) left the supported regime:%s%s%s%s%s%s", k, c->slot0 + k,
                           (st[k] & ST_LIST_OVERFLOW) ? " neighbour list overflow;" : "",
                           (st[k] & ST_BOX_TOO_SMALL) ? " box edge < 2*rc (minimum image invalid);" : "",
                           (st[k] & ST_TAPE_EXHAUSTED) ? " rng tape exhausted;" : "",
                           (st[k] & ST_NONFINITE) ? " non-finite energy;" : "",
-                          (st[k] & ST_SYNC_TIMEOUT) ? " cluster hand-off timed out (workgroups not co-resident?);" : "");
+                          (st[k] & ST_SYNC_TIMEOUT) ? " cluster hand-off timed out (workgroups not co-resident?);" : "",
+                          (st[k] & ST_NOT_RESIDENT) ? " the launch's workgroups were not resident together (CUs taken by another process, stream or a CU "
+                                                      "mask): nothing was changed, re-issue the block or lower NM_CUS_PER_REPLICA;" : "");
             return fail(c, NM_ERR_STATE, buf);
         }
     return NM_OK;
@@ -270,18 +299,53 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     } while (0)
     CHK(hipSetDevice(cfg->device));
     CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    // Workgroups per replica.  A cluster spins on its peers, so every workgroup of the grid must be resident at once: the
-    // small kernel admits one workgroup per CU (LDS + registers), so nslots*Q must not exceed the CU count (with a margin).
-    c->cus = 1; c->d_xbuf = nullptr; c->launch_id = 0;
+    // Workgroups per replica.  A cluster spins on its peers, so every workgroup of the grid must be resident at once.  The
+    // candidates are the Q for which the occupancy query admits the whole grid (workgroups per CU x CUs); the first one whose
+    // grid actually gathers in a residency census (a probe launch of the block kernel that leaves right after signing in,
+    // nm_kernels.h) is taken, so a masked or busy CU lowers Q here instead of stalling every block.  Every later launch runs
+    // the same census and leaves with ST_NOT_RESIDENT, state untouched, if the grid does not gather.
+    c->cus = 1; c->d_xbuf = nullptr; c->launch_id = 0; c->d_census = nullptr;
+    std::string note;
     {
         hipDeviceProp_t prop;
         CHK(hipGetDeviceProperties(&prop, cfg->device));
-        const int cu = prop.multiProcessorCount;
+        int cu = prop.multiProcessorCount;
+        if (const char *e = std::getenv("NM_ASSUME_CUS")) { const int v = std::atoi(e); if (v > 0) cu = v; } // tests of the fallback
         int want = 8;
         if (const char *e = std::getenv("NM_CUS_PER_REPLICA")) want = std::atoi(e);
         const int maxq = c->kind == 0 ? (c->pot == 0 ? 8 : 4) : c->kind == 1 ? 8 : 2; // own-atom ranges the instantiated thread mappings cover
-        for (int qq : { 8, 4, 2 })
-            if (qq <= maxq && want >= qq && c->nslots * qq <= cu) { c->cus = qq; break; }
+        CHK(dalloc(&c->d_census, 1));
+        CHK(dalloc(&c->d_status, (size_t)c->nslots));
+        CHK(hipMemset(c->d_status, 0, sizeof(int) * c->nslots));
+        CHK(dalloc(&c->d_slot2buf, (size_t)c->nslots));
+        {
+            std::vector<int> ident((size_t)c->nslots);
+            for (int k = 0; k < c->nslots; ++k) ident[k] = k;
+            CHK(hipMemcpy(c->d_slot2buf, ident.data(), sizeof(int) * c->nslots, hipMemcpyHostToDevice));
+        }
+        for (int qq : { 8, 4, 2 }) {
+            if (qq > maxq || want < qq) continue;
+            const int per_cu = blocks_per_cu_kind(c->kind, c->pot, qq);
+            if ((long)c->nslots * qq > (long)per_cu * cu) continue;
+            // probe: does the grid of this Q gather?
+            c->cus = qq;
+            KParams p;
+            fill_params(c, p);
+            p.census_only = 1;
+            CHK(launch_kind(c, p));
+            CHK(hipStreamSynchronize(c->stream));
+            std::vector<int> st((size_t)c->nslots);
+            CHK(hipMemcpy(st.data(), c->d_status, sizeof(int) * c->nslots, hipMemcpyDeviceToHost));
+            bool ok = true;
+            for (int v : st) ok = ok && !(v & ST_NOT_RESIDENT);
+            if (ok) break;
+            CHK(hipMemset(c->d_status, 0, sizeof(int) * c->nslots));
+            char buf[200];
+            std::snprintf(buf, sizeof buf, "nm_create: %d workgroups per replica (%d in all) did not gather on this device; falling back. ",
+                          qq, c->nslots * qq);
+            note += buf;
+            c->cus = 1;
+        }
         if (c->kind == 1 && c->cus == 8) { c->aux_doubles = CfgMidQ8::AUX_DOUBLES; c->lds_bytes = CfgMidQ8::LDS_BYTES; }
     }
     const size_t ns = c->nslots, n3 = (size_t)3 * c->N;
@@ -290,7 +354,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     CHK(dalloc(&c->d_count, ns * 6)); CHK(dalloc(&c->d_ratio, ns * 3));
     CHK(dalloc(&c->d_et, ns)); CHK(dalloc(&c->d_pf, ns)); CHK(dalloc(&c->d_tq, ns));
     CHK(dalloc(&c->d_stats, ns * NM_STATS_COLS));
-    CHK(dalloc(&c->d_slot2buf, ns)); CHK(dalloc(&c->d_status, ns)); CHK(dalloc(&c->d_nswaps, 1));
+    CHK(dalloc(&c->d_nswaps, 1)); // (d_slot2buf, d_status: allocated for the census probe above)
     CHK(dalloc(&c->d_evalU, ns)); CHK(dalloc(&c->d_evalW, ns)); CHK(dalloc(&c->d_evalF, ns * n3));
     const int npairs = c->cfg.nrows * cfg->nt * (cfg->nt - 1) / 2;
     CHK(dalloc(&c->d_xcrit, (size_t)npairs)); CHK(dalloc(&c->d_xtape, (size_t)npairs));
@@ -311,10 +375,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     CHK(hipMemset(c->d_box, 0, ns * sizeof(double))); CHK(hipMemset(c->d_steps, 0, ns * 3 * sizeof(double)));
     CHK(hipMemset(c->d_therm, 0, ns * 5 * sizeof(double))); CHK(hipMemset(c->d_count, 0, ns * 6 * sizeof(double)));
     CHK(hipMemset(c->d_ratio, 0, ns * 3 * sizeof(float))); CHK(hipMemset(c->d_stats, 0, ns * NM_STATS_COLS * sizeof(double)));
-    CHK(hipMemset(c->d_status, 0, ns * sizeof(int))); CHK(hipMemset(c->d_nswaps, 0, sizeof(int)));
-    std::vector<int> ident(ns);
-    for (size_t k = 0; k < ns; ++k) ident[k] = (int)k;
-    CHK(hipMemcpy(c->d_slot2buf, ident.data(), ns * sizeof(int), hipMemcpyHostToDevice));
+    CHK(hipMemset(c->d_nswaps, 0, sizeof(int)));
     CHK(hipMemcpy(c->d_et, c->h_et.data(), ns * sizeof(double), hipMemcpyHostToDevice));
     CHK(hipMemcpy(c->d_pf, c->h_pf.data(), ns * sizeof(double), hipMemcpyHostToDevice));
     CHK(hipMemcpy(c->d_tq, c->h_tq.data(), ns * sizeof(double), hipMemcpyHostToDevice));
@@ -338,6 +399,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     c->ev.resize(32);
     for (auto &e : c->ev) { CHK(hipEventCreate(&e.a)); CHK(hipEventCreate(&e.b)); e.used = false; }
 #undef CHK
+    c->err = note; // nm_last_error(ctx) after a successful nm_create: what the residency probe had to give up, if anything
     *out = c;
     return NM_OK;
 }
@@ -350,7 +412,7 @@ int nm_destroy(nm_ctx *c)
     for (auto &e : c->ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     void *ptrs[] = { c->d_x, c->d_v, c->d_box, c->d_steps, c->d_therm, c->d_count, c->d_ratio, c->d_et, c->d_pf, c->d_tq,
                      c->d_stats, c->d_slot2buf, c->d_status, c->d_nswaps, c->d_evalU, c->d_evalW, c->d_evalF, c->d_xcrit,
-                     c->d_xtape, c->d_tape, c->d_tape_off, c->d_trace, c->d_nbr, c->d_aux, c->d_prof, c->d_tline, c->d_xbuf };
+                     c->d_xtape, c->d_tape, c->d_tape_off, c->d_trace, c->d_nbr, c->d_aux, c->d_prof, c->d_tline, c->d_xbuf, c->d_census };
     for (void *q : ptrs) if (q) hipFree(q);
     if (c->h_stage) hipHostFree(c->h_stage);
     hipStreamDestroy(c->stream);
@@ -570,6 +632,15 @@ int nm_synchronize(nm_ctx *c)
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_status(c);
+}
+
+int nm_get_status(nm_ctx *c, int *status)
+{
+    if (!c || !status) return fail(c, NM_ERR_ARG, "nm_get_status: null argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(status, c->d_status, sizeof(int) * c->nslots, hipMemcpyDeviceToHost));
+    return NM_OK;
 }
 
 int nm_timing_reset(nm_ctx *c)

@@ -15,7 +15,7 @@ enum : uint32_t { S_ROLL = 0, S_ACC = 1, S_VOL = 2, S_DISP_XY = 3, S_DISP_Z = 4,
                   S_EXCH = 7, S_ITER_XY = 8, S_ITER_Z = 9, S_ITER_ACC = 10 };
 
 // status bits per slot
-enum : int { ST_LIST_OVERFLOW = 1, ST_BOX_TOO_SMALL = 2, ST_TAPE_EXHAUSTED = 4, ST_NONFINITE = 8, ST_SYNC_TIMEOUT = 16 };
+enum : int { ST_LIST_OVERFLOW = 1, ST_BOX_TOO_SMALL = 2, ST_TAPE_EXHAUSTED = 4, ST_NONFINITE = 8, ST_SYNC_TIMEOUT = 16, ST_NOT_RESIDENT = 32 };
 
 struct KParams {
     int N, nslots, slot0;          // atoms, local replicas, global index of local slot 0
@@ -50,6 +50,8 @@ struct KParams {
     unsigned long long *tline;     // experiment build only: 100 MHz timestamps of slot 0's evaluations [q][wave][eval][8]
     double *xbuf;                  // [slot][2][XBUF_DOUBLES]: force slices + partial sums exchanged inside a cluster
     uint32_t launch_id;            // distinguishes the granules of successive launches
+    unsigned int *census;          // cluster launches: arrival counter of the grid's workgroups (zeroed before the launch)
+    int census_only;               // nm_create's residency probe: leave right after the census
 };
 
 // ------------------------------------------------------------------------------------------ Philox4x32-10

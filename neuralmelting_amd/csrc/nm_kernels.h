@@ -1401,6 +1401,40 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
     const bool writer = (tid == 0 && qq == 0); // one workgroup of the cluster writes the replica's results
     const int N = p.N;
 
+    // Residency census (clusters only).  The workgroups of a cluster spin on one another, so the whole grid must be resident at
+    // once; HIP promises nothing of the kind, and a CU taken by another process, a CU mask or a second stream would leave part of
+    // the grid queued behind workgroups that wait for it.  Every workgroup signs in on one counter and waits (bounded: 200 us)
+    // until all have; whoever gives up sets an abort bit that also fails every later arrival, so the verdict is unanimous.  On
+    // failure nothing has been touched yet: the block leaves with ST_NOT_RESIDENT and the state in HBM is what it was.
+    if (Q > 1 && p.census) {
+        constexpr unsigned int ABORT = 0x80000000u;
+        int *flag = (int *)(nm_lds + C::OFF_RED);
+        if (tid == 0) {
+            const unsigned int want = gridDim.x;
+            atomicAdd(p.census, 1u);
+            const unsigned long long t0 = wall_clock64();
+            int ok = 0;
+            for (;;) {
+                const unsigned int v = __hip_atomic_load(p.census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v == want) { ok = 1; break; }
+                if (v & ABORT) break;
+                if (wall_clock64() - t0 > 20000ull) { // 200 us of the 100 MHz clock
+                    ok = (atomicOr(p.census, ABORT) == want) ? 1 : 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            *flag = ok;
+        }
+        __syncthreads();
+        const int ok = *flag;
+        __syncthreads(); // the slot is reused by the reductions
+        if (!ok) {
+            if (writer) p.status[slot] |= ST_NOT_RESIDENT;
+            return;
+        }
+        if (p.census_only) return;
+    }
 #ifdef NM_EXPERIMENT
     const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_w0 = wall_clock64();
 #endif
@@ -1607,6 +1641,13 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
         double k4[4] = { R.own_mv2(), 0.0, 0.0, 0.0 };
         if (!(R.status & fatal)) R.template exchange_sums<4>(k4); // (a cluster that is leaving on an error is no longer in step)
         smv2 = k4[0];
+    }
+    // A block that ends on an error leaves the replica's state in HBM as it was when the block started (nothing below runs): the
+    // host reports the reason, and a caller that can cure it (fewer workgroups per replica after a hand-over timeout) may
+    // re-issue the block.
+    if (R.status & fatal) {
+        if (writer) p.status[slot] |= R.status;
+        return;
     }
     R.store(buf);
     if (writer) {

@@ -147,6 +147,12 @@ class Engine:
     def synchronize(self):
         self._chk(self.lib.nm_synchronize(self.h))
 
+    def status(self):
+        """per-slot status bits (include/nm.h NM_ST_*) of the last block; 0 = fine"""
+        st = np.empty(self.nslots, dtype=np.int32)
+        self._chk(self.lib.nm_get_status(self.h, st.ctypes.data_as(B.c_int_p)))
+        return st
+
     # -- measurement
     def timing_reset(self):
         self._chk(self.lib.nm_timing_reset(self.h))

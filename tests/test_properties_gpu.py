@@ -124,6 +124,71 @@ def test_list_overflow_is_reported_by_the_whole_cluster_without_timeouts(np_rows
     e.close()
 
 
+def test_grid_that_cannot_be_resident_falls_back_to_fewer_workgroups_per_replica(monkeypatch):
+    """Cluster launch safety.  NM_ASSUME_CUS makes nm_create believe the chip has 512 CUs, so it first tries 8 workgroups per
+    replica for 64 replicas = 512 workgroups of 82 KB LDS each, twice what the chip can hold at once.  The residency probe
+    (a census launch) must see that the grid does not gather, fall back to 4 per replica, say so in nm_last_error, and the
+    chains must then be the ones a plain 4-per-replica context produces — no 2 s hand-over timeouts, no hang."""
+    import time
+    import neuralmelting_amd as nm
+    from neuralmelting_amd import lattice
+    P, T = grids(8, 8)
+    x, v, box, d = lattice.init_states(4, P, T, 0.03125, 0.03125)
+    outs = []
+    for assume in ('512', None):
+        if assume:
+            monkeypatch.setenv('NM_ASSUME_CUS', assume)
+        else:
+            monkeypatch.delenv('NM_ASSUME_CUS')
+        t0 = time.perf_counter()
+        e = nm.Engine(256, P, T)
+        note = e.lib.nm_last_error(e.h).decode()
+        assert e.cus_per_replica == 4
+        if assume:
+            assert '8 workgroups per replica (512 in all) did not gather' in note
+            assert time.perf_counter() - t0 < 1.0
+        else:
+            assert note == ''
+        e.set_state(x, v, box, d)
+        e.run_block(16)
+        outs.append(e.thermo())
+        e.close()
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_a_block_that_ends_on_an_error_leaves_the_state_as_it_was(monkeypatch):
+    """whatever stops a block (here an injected list overflow at the sixth rebuild, i.e. in the middle of it): x, v, box of the
+    slots that stopped are those of the block's start, so a caller can inspect or re-issue; slots that finished have moved on"""
+    import ctypes as C
+    import neuralmelting_amd as nm
+    from neuralmelting_amd import lattice
+    P, T = grids(8, 8)
+    x, v, box, d = lattice.init_states(4, P, T, 0.03125, 0.03125)
+    e = nm.Engine(256, P, T)
+    e.set_state(x, v, box, d)
+    e.run_block(8)
+    e.synchronize()
+    x1, v1, box1, d1 = e.get_state()
+    monkeypatch.setenv('NM_INJECT_OVERFLOW', '5,1')
+    e.set_step(1)
+    e.run_block(48)
+    with pytest.raises(nm.NMError):
+        e.synchronize()
+    monkeypatch.delenv('NM_INJECT_OVERFLOW')
+    st = e.status()
+    stopped = st != 0
+    assert stopped.sum() >= 32 and (st[stopped] == 1).all()                # NM_ST_LIST_OVERFLOW
+    xo, vo, bo = np.empty((64, 768)), np.empty((64, 768)), np.empty(64)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    rc = e.lib.nm_get_state(e.h, 0, 64, dp(xo), dp(vo), dp(bo), None)     # the copy succeeds; the return code repeats the error
+    assert rc == -3
+    np.testing.assert_array_equal(xo[stopped], x1[stopped])
+    np.testing.assert_array_equal(vo[stopped], v1[stopped])
+    np.testing.assert_array_equal(bo[stopped], box1[stopped])
+    assert (np.abs(xo[~stopped] - x1[~stopped]).max(1) > 0).all()          # the others completed their 48 moves
+    e.close()
+
+
 def test_box_smaller_than_twice_the_cutoff_is_refused():
     nm, e = _dense_engine(8, 8, 4.9)
     with pytest.raises(nm.NMError) as err:
