@@ -2,9 +2,18 @@
 
 A step = one cycle of the reference's main loop (remcmc:977-995) with outputs off (-sc == -sn, as run.sh:7):
 gen_samples (MOD moves per replica) -> gen_mc_params -> replica_exchange.  One sweep = one move_mc call on one
-replica, so a step is NS*MOD sweeps.  Workload at N=1: BASELINE configs[1] — LJ, 4^3 cells (256 atoms), 8x8 PxT grid,
-64 replicas resident in HBM.  For N>1 every rank owns 8 pressure rows x 8 temperatures of an (8N)x8 grid
-(weak scaling; the exchange never crosses pressure rows, so there is no data-path collective).
+replica, so a step is NS*MOD sweeps.
+
+Workloads (--config; BASELINE.json `configs`):
+  C2    LJ 4^3 cells (256 atoms), 8x8 PxT grid: the configuration the metric is quoted on (default)
+  C3    LJ 6^3 cells (864 atoms), 16x16 grid over 8 GPUs: one GPU's share = 2 pressure rows x 16 temperatures
+  C4    Al (Sutton-Chen EAM, metal units) 4^3 cells, 8x8 grid
+  C5    LJ 8^3 cells (2048 atoms), 32x32 grid over 8 GPUs: one GPU's share = 4 rows x 32 temperatures
+  runsh LJ 5^3 cells (500 atoms), 32x32 grid: the reference's own production setting (run.sh:1,7,10), whole grid on one GPU
+--scaling weak (default): every rank holds `rows` pressure rows of a (rows x N)-row grid, so per-GPU work is fixed; the exchange
+never leaves a pressure row, so there is no data-path collective.  --scaling strong: the config's own grid (C2: 8x8) is
+dealt out over the ranks — whole rows while they last, else even slot ranges with the split-row exchange over RCCL
+(neuralmelting_amd/exchange.py).
 """
 import argparse
 import json
@@ -19,8 +28,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
-FP64_VEC_PEAK_TF = 78.6    # MI355X fp64 vector peak (spec; = FP32 vector 157.3 / 2)
+FP64_VEC_PEAK_TF = 78.6    # MI355X fp64 vector peak = 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz (spec)
 FLOP_PER_PAIR = 40.0
+
+# name: (element, supercell, pressure rows per GPU, rows of the whole grid, temperatures, MOD, description)
+CONFIGS = {
+    'C2': ('LJ', 4, 8, 8, 8, 128, 'BASELINE config 2: LJ 4^3 cells (256 atoms), 8x8 PxT grid'),
+    'C3': ('LJ', 6, 2, 16, 16, 128, "BASELINE config 3, one GPU's share: LJ 6^3 cells (864 atoms), 2 of the 16x16 grid's pressure rows"),
+    'C4': ('Al', 4, 8, 8, 8, 128, 'BASELINE config 4: Al (Sutton-Chen EAM) 4^3 cells (256 atoms), 8x8 PxT grid'),
+    'C5': ('LJ', 8, 4, 32, 32, 128, "BASELINE config 5, one GPU's share: LJ 8^3 cells (2048 atoms), 4 of the 32x32 grid's pressure rows"),
+    'runsh': ('LJ', 5, 32, 32, 32, 128, "the reference's run.sh setting: LJ 5^3 cells (500 atoms), 32x32 PxT grid"),
+}
 
 
 def main():
@@ -28,14 +46,22 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=8)
-    ap.add_argument('--sz', type=int, default=4, help='supercell size (-ss)')
-    ap.add_argument('--rows', type=int, default=8, help='pressure rows per GPU')
-    ap.add_argument('--tn', type=int, default=8, help='temperatures (-tn)')
-    ap.add_argument('--mod', type=int, default=128, help='moves per block (-sm)')
-    ap.add_argument('--el', type=str, default='LJ', help="element (-e): LJ, or Al = BASELINE config 4 (Sutton-Chen EAM, metal units)")
+    ap.add_argument('--config', type=str, default='C2', choices=sorted(CONFIGS), help='workload preset (see the module docstring)')
+    ap.add_argument('--scaling', type=str, default='weak', choices=('weak', 'strong'))
+    ap.add_argument('--sz', type=int, default=None, help='override: supercell size (-ss)')
+    ap.add_argument('--rows', type=int, default=None, help='override: pressure rows per GPU')
+    ap.add_argument('--tn', type=int, default=None, help='override: temperatures (-tn)')
+    ap.add_argument('--mod', type=int, default=None, help='override: moves per block (-sm)')
+    ap.add_argument('--el', type=str, default=None, help='override: element (-e), LJ or Al')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
-    ap.add_argument('--cpu-cycles', type=int, default=4)
+    ap.add_argument('--cpu-seconds', type=float, default=6.0, help='target wall time of each cpu_baseline leg')
     args = ap.parse_args()
+
+    el, sz, rows, np_cfg, tn, mod, desc = CONFIGS[args.config]
+    custom = any(v is not None for v in (args.sz, args.rows, args.tn, args.mod, args.el))
+    el, sz, rows, tn, mod = args.el or el, args.sz or sz, args.rows or rows, args.tn or tn, args.mod or mod
+    if custom:
+        np_cfg, desc = rows, 'custom workload'
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -46,6 +72,7 @@ def main():
                              % (args.gpus, args.gpus))
     import torch
     dist = None
+    backend = None
     if world > 1 or 'RANK' in os.environ:  # under torch.distributed.run: one rank per GPU over RCCL (also at N=1)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -61,24 +88,66 @@ def main():
             dist.init_process_group(backend)
 
     import neuralmelting_amd as nm
-    from neuralmelting_amd import lattice
+    from neuralmelting_amd import lattice, exchange as X
 
-    npn = args.rows * world
+    # ---- which replicas this rank holds
+    split = False
+    if args.scaling == 'weak':
+        npn = rows * world
+        row0, nrows = rank * rows, rows
+    else:
+        npn = np_cfg if not custom else rows
+        if npn % world == 0:
+            nrows = npn // world
+            row0 = rank * nrows
+        elif (npn * tn) % world == 0:  # fewer rows than ranks: even slot ranges, a pressure row spans ranks
+            split = True
+        else:
+            raise SystemExit('strong scaling: %d x %d replicas do not divide over %d ranks' % (npn, tn, world))
     P = np.linspace(1.0, 8.0, npn, dtype=np.float32)
-    T = np.linspace(0.25, 2.5, args.tn, dtype=np.float32) if args.el == 'LJ' else np.linspace(256.0, 2560.0, args.tn, dtype=np.float32)
-    natoms = 4 * args.sz ** 3
-    row0 = rank * args.rows
-    x, v, box, d = lattice.init_states(args.sz, P, T, 0.03125, 0.03125, el=args.el, row0=row0, nrows=args.rows)
-    eng = nm.Engine(natoms, P, T, element=args.el, device=local, row0=row0, nrows=args.rows, ppos=0.125, pvol=0.125, nstps=8,
-                    bulk=True, seed=256)
+    T = np.linspace(0.25, 2.5, tn, dtype=np.float32) if el == 'LJ' else np.linspace(256.0, 2560.0, tn, dtype=np.float32)
+    natoms = 4 * sz ** 3
+    kw = dict(element=el, device=local, ppos=0.125, pvol=0.125, nstps=8, bulk=True, seed=256)
+    if split:
+        nloc = npn * tn // world
+        k0 = rank * nloc
+        r0, r1 = k0 // tn, (k0 + nloc - 1) // tn
+        x, v, box, d = lattice.init_states(sz, P, T, 0.03125, 0.03125, el=el, row0=r0, nrows=r1 - r0 + 1)
+        a = k0 - r0 * tn
+        x, v, box, d = x[a:a + nloc], v[a:a + nloc], box[a:a + nloc], d[a:a + nloc]
+        eng = nm.Engine(natoms, P, T, slot0=k0, nslots=nloc, **kw)
+    else:
+        x, v, box, d = lattice.init_states(sz, P, T, 0.03125, 0.03125, el=el, row0=row0, nrows=nrows)
+        eng = nm.Engine(natoms, P, T, row0=row0, nrows=nrows, **kw)
+        k0 = row0 * tn
     eng.set_state(x, v, box, d)
     ns = eng.nslots
+    if split:
+        from neuralmelting_amd import remcmc
+        et_all = np.array([remcmc.init_constant(P, T, el, *divmod(k, tn))[0] for k in range(npn * tn)])
+        pf_all = np.array([remcmc.init_constant(P, T, el, *divmod(k, tn))[1] for k in range(npn * tn)])
+        info = (world, backend == 'nccl')
 
-    def cycle(step, last=False):
+    def exchange_split(step):
+        """a pressure row spans ranks: all-gather (E_tot, V), identical sweep everywhere, re-seat what moved (exchange.py)"""
+        r = eng.thermo()
+        ev = X.allgather(np.stack([r[:, 1] + r[:, 2], r[:, 4]], axis=1), info)
+        perm, swaps = X.sweep(npn, tn, 256, step, ev[:, 0], ev[:, 1], et_all, pf_all)
+        if swaps:
+            xs, vs, bs, ds = eng.get_state()
+            pack = np.concatenate([xs, vs, bs[:, None], ds, r[:, :5]], axis=1)
+            allp = X.allgather(pack, info)[perm[k0:k0 + ns]]
+            n3 = 3 * natoms
+            eng.set_state(allp[:, :n3], allp[:, n3:2 * n3], allp[:, 2 * n3], allp[:, 2 * n3 + 1:2 * n3 + 4])
+            eng.set_thermo(allp[:, 2 * n3 + 4:2 * n3 + 9])
+
+    def cycle(step):
         eng.set_step(step)
-        eng.run_block(args.mod)
+        eng.run_block(mod)
         eng.adapt()
-        if not last:
+        if split:
+            exchange_split(step)
+        else:
             eng.exchange(count=False)
 
     def fence():
@@ -101,57 +170,70 @@ def main():
         step += 1
     fence()
     dt = time.perf_counter() - t0
+    ns_total = ns
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        tt = torch.tensor([dt, float(ns)], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)
+        dt, ns_total = float(tt[0].item()), int(round(float(tt[1].item())))
+        world_seen = dist.get_world_size()
+    else:
+        world_seen = 1
 
     launches, kms = eng.timing()
     st = eng.stats()
     # one more block outside the timed region, read before gen_mc_params zeroes the counters: the per-replica acceptance
     # ratios and U, V the metric's definition asks to see next to the rate
     eng.set_step(step)
-    eng.run_block(args.mod)
+    eng.run_block(mod)
     last = eng.thermo()
-    sweeps_total = world * ns * args.mod * args.steps
+    sweeps_total = ns_total * mod * args.steps
     value = sweeps_total / dt
 
     out = None
     if rank == 0:
         # dominant kernel: nm_block_kernel, one launch per step, ns*mod sweeps per launch
         phmc = 1.0 - 0.125 - 0.125
-        bytes_per_sweep = 48.0 * natoms + 24.0 * natoms * phmc          # SURVEY.md §8d compulsory HBM bytes
+        evals_alg = 0.125 + 0.125 + phmc * 9.0                             # EVALS = PPOS + PVOL + PHMC (NSTPS + 1) = 7.0
+        bytes_per_sweep = 48.0 * natoms + 24.0 * natoms * phmc             # SURVEY.md §8d compulsory HBM bytes
         k_avg_s = (kms / max(launches, 1)) * 1e-3
-        sweeps_per_launch = ns * args.mod
+        sweeps_per_launch = ns * mod
         achieved_gbs = bytes_per_sweep * sweeps_per_launch / k_avg_s / 1e9
         evals = st[:, 0].sum()
         mean_pairs = st[:, 3].sum() / max(st[:, 2].sum(), 1.0)
-        flops = evals * mean_pairs * FLOP_PER_PAIR
-        tf = flops / (kms * 1e-3) / 1e12
+        tf_exec = evals * mean_pairs * FLOP_PER_PAIR / (kms * 1e-3) / 1e12
+        flop_alg_launch = evals_alg * sweeps_per_launch * mean_pairs * FLOP_PER_PAIR
+        tf_alg = flop_alg_launch / k_avg_s / 1e12
+        prof = measured_profile(args.config if not custom else None, ns, mod)
+        grid = '%dx%d PxT grid%s' % (npn, tn, '' if world == 1 else ' over %d GPUs' % world)
+        metric = 'MC sweeps/sec (whole node), %s %d^3 cells, %s' % (el, sz, grid)
         out = {
-            'metric': 'MC sweeps/sec (whole node), %s 4^3 cells, 8x8 PxT grid' % args.el,
-            'value': value, 'unit': 'sweeps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'metric': metric, 'value': value, 'unit': 'sweeps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': '%s %d^3 cells (%d atoms), %dx%d PxT grid per GPU, MOD=%d, bulk PMC 0.125 / VMC 0.125 / '
-                                   'HMC 0.75 x %d steps, outputs off' % (args.el, args.sz, natoms, args.rows, args.tn, args.mod, 8),
-                       'replicas_per_gpu': ns, 'sweeps_per_step': world * ns * args.mod, 'parallelism': 'rows/gpu'},
-            'roofline': {'bound': 'hbm', 'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved_gbs / HBM_PEAK_GBS, 'traffic': measured_traffic(natoms, ns, args.mod),
+            'config': {'workload': '%s; %s %d^3 cells (%d atoms), %d replicas on rank 0 (%d in all), MOD=%d, bulk PMC 0.125 / VMC '
+                                   '0.125 / HMC 0.75 x 8 steps, outputs off' % (desc, el, sz, natoms, ns, ns_total, mod),
+                       'preset': args.config if not custom else None, 'replicas_per_gpu': ns, 'replicas_total': ns_total,
+                       'sweeps_per_step': ns_total * mod,
+                       'parallelism': ('rows/gpu' if not split else 'slots/gpu, split-row exchange over %s' % backend),
+                       'world_size_seen_by_backend': world_seen, 'backend': backend},
+            # The binding roofline: the working set is LDS-resident, so the ceiling is fp64 vector issue.
+            # achieved = algorithmic flops per launch (7.0 evaluations per sweep x measured interacting pairs x 40 flop) / the
+            # kernel's HIP-event time; traffic = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/).
+            'roofline': {'bound': 'fp64-valu', 'achieved': tf_alg, 'peak': FP64_VEC_PEAK_TF, 'unit': 'TFLOP/s',
+                         'frac': tf_alg / FP64_VEC_PEAK_TF, 'traffic': prof.get('traffic'),
                          'kernel': 'nm_block_kernel', 'kernel_avg_ms': k_avg_s * 1e3, 'launches': launches,
-                         'algorithmic_bytes_per_launch': bytes_per_sweep * sweeps_per_launch,
-                         'note': 'LDS-resident by design: the binding ceiling is fp64 VALU/latency on the CUs that hold a '
-                                 'replica, see fp64'},
-            # executed work (evaluations the kernel really made) and SURVEY.md §8d's algorithmic count
-            # EVALS = PPOS + PVOL + PHMC (NSTPS + 1) = 7.0 per sweep at the defaults (the kernel makes fewer: forces are kept
-            # across accepted and rejected moves)
-            'fp64': {'achieved': tf, 'peak': FP64_VEC_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tf / FP64_VEC_PEAK_TF,
-                     'algorithmic_evals_per_sweep': 0.125 + 0.125 + phmc * 9.0,
-                     'achieved_algorithmic': (0.125 + 0.125 + phmc * 9.0) * sweeps_per_launch * mean_pairs * FLOP_PER_PAIR
-                                             / k_avg_s / 1e12,
-                     'evals_per_sweep': evals / (ns * args.mod * args.steps), 'mean_pairs_per_eval': mean_pairs,
-                     'flop_per_pair': FLOP_PER_PAIR, 'list_rebuilds_per_sweep': st[:, 1].sum() / (ns * args.mod * args.steps),
-                     'cus_per_replica': eng.cus_per_replica, 'cus_occupied': ns * eng.cus_per_replica, 'cus_total': 256},
+                         'algorithmic_flop_per_launch': flop_alg_launch, 'algorithmic_evals_per_sweep': evals_alg,
+                         'executed': tf_exec, 'evals_per_sweep': evals / (ns * mod * args.steps),
+                         'mean_pairs_per_eval': mean_pairs, 'flop_per_pair': FLOP_PER_PAIR,
+                         'list_rebuilds_per_sweep': st[:, 1].sum() / (ns * mod * args.steps),
+                         'valu_active_share': prof.get('valu_active_share'), 'profile': prof.get('source'),
+                         'profile_commit': prof.get('commit'),
+                         'cus_per_replica': eng.cus_per_replica, 'cus_occupied': min(ns * eng.cus_per_replica, 256), 'cus_total': 256},
+            # the HBM line the contract asks for: algorithmic bytes (48 N + 24 N PHMC per sweep) / kernel time, << 1 % by design
+            'roofline_hbm': {'bound': 'hbm', 'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'frac': achieved_gbs / HBM_PEAK_GBS, 'traffic': prof.get('traffic'),
+                             'algorithmic_bytes_per_launch': bytes_per_sweep * sweeps_per_launch},
         }
         out['replicas'] = {'note': 'rank 0, block after the timed region, slot k = i*NT + j (pressure i, temperature j)',
                            'accept_pmc': [round(float(a), 3) for a in last[:, 14]],
@@ -160,7 +242,7 @@ def main():
                            'pe_per_atom': [round(float(a) / natoms, 4) for a in last[:, 1]],
                            'vol_per_atom': [round(float(a) / natoms, 4) for a in last[:, 4]]}
         if not args.no_cpu:
-            out['cpu_baseline'] = cpu_baseline(eng, natoms, args, T, P, row0)
+            out['cpu_baseline'] = cpu_baseline(eng, natoms, el, mod, T, tn, k0, args.cpu_seconds)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -169,18 +251,34 @@ def main():
         print(json.dumps(out))
 
 
-def measured_traffic(natoms, ns, mod):
-    """HBM bytes per launch of nm_block_kernel from the committed rocprofv3 PMC passes (profiles/), for the workload
-    they were taken on; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  None for other workloads."""
-    f = os.path.join(ROOT, 'profiles', 'r01_pmc_block_kernel_final.json')
-    if not (os.path.isfile(f) and natoms == 256 and ns == 64 and mod == 128):
-        return None
+def measured_profile(config, ns, mod):
+    """What the committed rocprofv3 PMC passes of this round say about nm_block_kernel on the preset's workload (profiles/,
+    written by scripts/collect_pmc.py together with the commit they were taken at): HBM bytes per launch — FETCH_SIZE doubled
+    as MI355X_MICROARCH.md prescribes for gfx950, KB units — and the share of SIMD cycles that issued VALU.  Empty for
+    workloads without a committed profile."""
+    if config is None:
+        return {}
+    f = os.path.join(ROOT, 'profiles', 'r02_pmc_block_kernel_%s.json' % config)
+    if not os.path.isfile(f):
+        return {}
     d = json.load(open(f))
-    return (2.0 * d['FETCH_SIZE']['mean'] + d['WRITE_SIZE']['mean']) * 1024.0
+    meta = d.get('_meta', {})
+    if meta.get('replicas') != ns or meta.get('mod') != mod:
+        return {}
+    out = {'source': 'profiles/' + os.path.basename(f), 'commit': meta.get('commit')}
+    if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
+        out['traffic'] = (2.0 * d['FETCH_SIZE']['mean'] + d['WRITE_SIZE']['mean']) * 1024.0
+    if 'SQ_ACTIVE_INST_VALU' in d and 'GRBM_GUI_ACTIVE' in d:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        cyc = d['GRBM_GUI_ACTIVE']['mean'] / 8.0
+        out['valu_active_share'] = 4.0 * d['SQ_ACTIVE_INST_VALU']['mean'] / (256 * 4 * cyc)
+    return out
 
 
-def cpu_baseline(eng, natoms, args, T, P, row0):
-    """the oracle (C restatement, OpenMP over replicas) timed on the host cores on the engine's current states"""
+def cpu_baseline(eng, natoms, el, mod, T, tn, k0, seconds):
+    """the oracle (C restatement of the same path, kind "port": the reference's own CPU path needs a LAMMPS build that is neither
+    in its tree nor in this image) timed on the host cores on the engine's post-warm-up states: (i) ONE thread on a bounded
+    sample of the replicas, (ii) OpenMP over replicas on all cores, each for about `seconds` of wall time"""
     from oracle import oracle as O
     from neuralmelting_amd import lattice
     O.build()
@@ -193,17 +291,33 @@ def cpu_baseline(eng, natoms, args, T, P, row0):
     except Exception:
         pass
     cores = min(cores, ns)  # one replica per thread: more threads than replicas would idle
-    t0 = time.perf_counter()
-    for c in range(args.cpu_cycles):
-        kw = dict(units=1, mass=lattice.MASS['Al'], pot=1) if args.el == 'Al' else {}
-        tq = np.tile(T.astype(np.float64), args.rows)
-        out = O.run_blocks(x, v, box, d, tq, et, pf, natoms=natoms, mod=args.mod, nstps=8, bulk=True, ppos=0.125,
-                           pvol=0.125, lat=lattice.LAT[args.el][1], seed=256, slot0=row0 * len(T), step=1000 + c, nthreads=cores, **kw)
-        x, v, box = out['x'], out['v'], out['box']
-    dt = time.perf_counter() - t0
-    return {'value': ns * args.mod * args.cpu_cycles / dt, 'unit': 'sweeps/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d cycles of the same %d-replica workload (MOD=%d) from the GPU run\'s post-warm-up states, '
-                      'OpenMP over replicas, %.1f s wall' % (args.cpu_cycles, ns, args.mod, dt)}
+    kw = dict(units=1, mass=lattice.MASS['Al'], pot=1) if el == 'Al' else {}
+    tq = np.tile(T.astype(np.float64), (ns + tn - 1) // tn + 1)[(k0 % tn):(k0 % tn) + ns]
+    common = dict(natoms=natoms, nstps=8, bulk=True, ppos=0.125, pvol=0.125, lat=lattice.LAT[el][1], seed=256, **kw)
+
+    def leg(sel, nthreads, mod_leg, budget):
+        xs, vs, bs = x[sel].copy(), v[sel].copy(), box[sel].copy()
+        n, t0, cyc = len(bs), time.perf_counter(), 0
+        while True:
+            o = O.run_blocks(xs, vs, bs, d[sel], tq[sel], et[sel], pf[sel], mod=mod_leg, slot0=k0 + int(sel[0]), step=1000 + cyc,
+                             nthreads=nthreads, **common)
+            xs, vs, bs = o['x'], o['v'], o['box']
+            cyc += 1
+            el_ = time.perf_counter() - t0
+            if el_ >= budget or cyc >= 64:
+                return n * mod_leg * cyc / el_, el_, cyc
+    # (i) one thread: a spread of replicas across the grid (cold solid ... hot fluid), blocks short enough to fit the budget
+    sel1 = np.unique(np.linspace(0, ns - 1, min(ns, 8)).astype(int))
+    mod1 = max(8, min(mod, 32))
+    r1, t1, c1 = leg(sel1, 1, mod1, seconds)
+    # (ii) all cores, all replicas
+    ra, ta, ca = leg(np.arange(ns), cores, mod, seconds)
+    return {'value': ra, 'unit': 'sweeps/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d cycles of the same %d-replica workload (MOD=%d) from the GPU run\'s post-warm-up states, OpenMP over '
+                      'replicas on %d threads, %.1f s wall' % (ca, ns, mod, cores, ta),
+            'single_thread': {'value': r1, 'unit': 'sweeps/s', 'cores': 1,
+                              'sample': '%d blocks of %d moves on %d replicas spread over the grid, one thread, %.1f s wall'
+                                        % (c1, mod1, len(sel1), t1)}}
 
 
 if __name__ == '__main__':

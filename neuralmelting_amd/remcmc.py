@@ -442,9 +442,13 @@ def main(argv=None):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         use_gpu = torch.cuda.is_available()
+        # one rank per GPU over RCCL.  NM_DIST_BACKEND=gloo: rehearsal with more ranks than cards (RCCL refuses two ranks on one
+        # device); the ranks then share the cards round-robin and the few host-side collectives go over gloo.
+        backend = os.environ.get('NM_DIST_BACKEND', 'nccl' if use_gpu else 'gloo')
         if use_gpu:
+            local = local % torch.cuda.device_count()
             torch.cuda.set_device(local)
-        dist.init_process_group('nccl' if use_gpu else 'gloo')
+        dist.init_process_group(backend)
     run = Run(argv, rank=rank, world=world, device=local)
     try:
         run.main()

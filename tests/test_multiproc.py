@@ -22,10 +22,12 @@ def free_port():
     return p
 
 
-def launch(nproc, cwd, argv):
+def launch(nproc, cwd, argv, script=None, extra_env=None):
+    """torch.distributed.run; by default the helper that swaps the oracle stand-in in, else `script` (a module path)"""
+    target = [os.path.join(HERE, '_mp_driver.py'), str(cwd)] if script is None else ['-m', script]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc),
-           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.join(HERE, '_mp_driver.py'), str(cwd)] + argv
-    env = dict(os.environ, OMP_NUM_THREADS='2')
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port())] + target + argv
+    env = dict(os.environ, OMP_NUM_THREADS='2', **(extra_env or {}))
     subprocess.run(cmd, check=True, timeout=600, env=env, cwd=str(cwd))
 
 
@@ -52,3 +54,32 @@ def test_two_ranks_equal_one_rank(tmp_path, oracle, npn, world):
         np.testing.assert_array_equal(sa[1], sb[1])
         assert [float(q) for q in sa[3:]] == [float(q) for q in sb[3:]]
     assert not [f for f in os.listdir(two) if '.part' in f]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('npn,world', [(2, 2), (1, 2)])  # whole rows per rank; one pressure row split across the two ranks
+def test_two_ranks_with_the_hip_engine_equal_one_rank(tmp_path, npn, world):
+    """The N>1 path with the REAL engine: two ranks (one process each, launched by torch.distributed.run before anything touches
+    the GPU) share the one card of this box, so the process group is gloo (RCCL refuses two ranks on one device); everything else
+    is the production path — each rank's own context and stream, the device-side exchange for whole rows, the all-gather +
+    identical-sweep + re-seat exchange when a row spans ranks — and must leave byte-identical files to a single-rank run."""
+    tn = 4 if npn == 1 else 2
+    argv = ('-bm -n mpg -e LJ -ss 4 -pn %d -tn %d -sn 4 -sm 8 -rd 1' % (npn, tn)).split()
+    if npn == 1:
+        argv += ['-tr', '1.0', '1.06']      # a narrow temperature range: the sweep does swap replicas across the two ranks
+    one = tmp_path / 'one'; two = tmp_path / 'two'
+    one.mkdir(); two.mkdir()
+    remcmc.Run(argv, cwd=str(one)).main()
+    launch(world, two, argv, script='neuralmelting_amd.remcmc', extra_env={'NM_DIST_BACKEND': 'gloo', 'PYTHONPATH': os.path.dirname(HERE)})
+    for ext in ('.thrm', '.traj'):
+        assert open(str(one / ('mpg.lj.fcc.lammps' + ext))).read() == open(str(two / ('mpg.lj.fcc.lammps' + ext))).read()
+    ra = np.load(str(one / 'mpg.lj.fcc.lammps.rstrt.0003.npy'), allow_pickle=True)
+    rb = np.load(str(two / 'mpg.lj.fcc.lammps.rstrt.0003.npy'), allow_pickle=True)
+    assert ra.shape == rb.shape == (npn * tn, 21)
+    for sa, sb in zip(ra, rb):
+        np.testing.assert_array_equal(sa[1], sb[1])
+        np.testing.assert_array_equal(sa[2], sb[2])
+        assert [float(q) for q in sa[3:]] == [float(q) for q in sb[3:]]
+    if npn == 1:                                # the split-row sweep really moved configurations between the ranks
+        th = np.loadtxt(str(two / 'mpg.lj.fcc.lammps.thrm'))
+        assert len(th) == npn * tn * 4
