@@ -118,7 +118,7 @@ void fill_params(const nm_ctx *c, KParams &p)
     p.nbr_g = c->d_nbr; p.aux_g = c->d_aux;
     p.prof = c->d_prof;
     p.cus = c->cus; p.xbuf = c->d_xbuf; p.launch_id = c->launch_id;
-    p.census = c->cus > 1 ? c->d_census : nullptr; p.census_only = 0;
+    p.census = c->cus > 1 ? c->d_census : nullptr;
     p.dbg = 0;
     p.tline = c->d_tline;
     if (const char *e = std::getenv("NM_DBG")) p.dbg = std::atoi(e);
@@ -137,6 +137,17 @@ hipError_t launch_block(const nm_ctx *c, const KParams &p)
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(nm_block_kernel<C>, dim3(c->nslots * c->cus), dim3(C::BLOCK), C::LDS_BYTES, c->stream, p);
+    return hipGetLastError();
+}
+
+template <class C>
+hipError_t launch_probe(const nm_ctx *c, const KParams &p)
+{
+    hipError_t e = hipFuncSetAttribute((const void *)nm_probe_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(c->d_census, 0, sizeof(unsigned int), c->stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(nm_probe_kernel<C>, dim3(c->nslots * c->cus), dim3(C::BLOCK), C::LDS_BYTES, c->stream, p);
     return hipGetLastError();
 }
 
@@ -169,6 +180,17 @@ int blocks_per_cu_kind(int kind, int pot, int q)
         return q == 8 ? blocks_per_cu<CfgSmallQ8>() : q == 4 ? blocks_per_cu<CfgSmallQ4>() : q == 2 ? blocks_per_cu<CfgSmallQ2>() : blocks_per_cu<CfgSmall>();
     case 1: return q == 8 ? blocks_per_cu<CfgMidQ8>() : q == 4 ? blocks_per_cu<CfgMidQ4>() : blocks_per_cu<CfgMid>();
     default: return blocks_per_cu<CfgLarge>();
+    }
+}
+
+hipError_t probe_kind(const nm_ctx *c, const KParams &p)
+{
+    switch (c->kind) {
+    case 0:
+        if (c->pot == 1) return c->cus == 4 ? launch_probe<CfgSmallSCQ4>(c, p) : c->cus == 2 ? launch_probe<CfgSmallSCQ2>(c, p) : launch_probe<CfgSmallSC>(c, p);
+        return c->cus == 8 ? launch_probe<CfgSmallQ8>(c, p) : c->cus == 4 ? launch_probe<CfgSmallQ4>(c, p) : c->cus == 2 ? launch_probe<CfgSmallQ2>(c, p) : launch_probe<CfgSmall>(c, p);
+    case 1: return c->cus == 8 ? launch_probe<CfgMidQ8>(c, p) : c->cus == 4 ? launch_probe<CfgMidQ4>(c, p) : launch_probe<CfgMid>(c, p);
+    default: return launch_probe<CfgLarge>(c, p);
     }
 }
 
@@ -301,7 +323,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     // Workgroups per replica.  A cluster spins on its peers, so every workgroup of the grid must be resident at once.  The
     // candidates are the Q for which the occupancy query admits the whole grid (workgroups per CU x CUs); the first one whose
-    // grid actually gathers in a residency census (a probe launch of the block kernel that leaves right after signing in,
+    // grid actually gathers in a residency census (nm_probe_kernel: the block kernel's launch shape, census only,
     // nm_kernels.h) is taken, so a masked or busy CU lowers Q here instead of stalling every block.  Every later launch runs
     // the same census and leaves with ST_NOT_RESIDENT, state untouched, if the grid does not gather.
     c->cus = 1; c->d_xbuf = nullptr; c->launch_id = 0; c->d_census = nullptr;
@@ -331,8 +353,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
             c->cus = qq;
             KParams p;
             fill_params(c, p);
-            p.census_only = 1;
-            CHK(launch_kind(c, p));
+            CHK(probe_kind(c, p));
             CHK(hipStreamSynchronize(c->stream));
             std::vector<int> st((size_t)c->nslots);
             CHK(hipMemcpy(st.data(), c->d_status, sizeof(int) * c->nslots, hipMemcpyDeviceToHost));

@@ -51,7 +51,6 @@ struct KParams {
     double *xbuf;                  // [slot][2][XBUF_DOUBLES]: force slices + partial sums exchanged inside a cluster
     uint32_t launch_id;            // distinguishes the granules of successive launches
     unsigned int *census;          // cluster launches: arrival counter of the grid's workgroups (zeroed before the launch)
-    int census_only;               // nm_create's residency probe: leave right after the census
 };
 
 // ------------------------------------------------------------------------------------------ Philox4x32-10

@@ -1379,6 +1379,51 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
     eacc -= 2.0 * eps * cc * sq_own;
 }
 
+// Residency census (clusters only).  The workgroups of a cluster spin on one another, so the whole grid must be resident at once;
+// HIP promises nothing of the kind, and a CU taken by another process, a CU mask or a second stream would leave part of the grid
+// queued behind workgroups that wait for it.  Every workgroup signs in on one counter and waits (bounded: 200 us) until all have;
+// whoever gives up sets an abort bit that also fails every later arrival, so the verdict is unanimous.  Returns false when the
+// grid did not gather; the caller has touched nothing by then.
+template <class C>
+__device__ __forceinline__ bool residency_census(const KParams &p)
+{
+    constexpr unsigned int ABORT = 0x80000000u;
+    int *flag = (int *)(nm_lds + C::OFF_RED);
+    if (threadIdx.x == 0) {
+        const unsigned int want = gridDim.x;
+        atomicAdd(p.census, 1u);
+        const unsigned long long t0 = wall_clock64();
+        int ok = 0;
+        for (;;) {
+            const unsigned int v = __hip_atomic_load(p.census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v == want) { ok = 1; break; }
+            if (v & ABORT) break;
+            if (wall_clock64() - t0 > 20000ull) { // 200 us of the 100 MHz clock
+                ok = (atomicOr(p.census, ABORT) == want) ? 1 : 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        *flag = ok;
+    }
+    __syncthreads();
+    const int ok = *flag;
+    __syncthreads(); // the slot is reused by the reductions
+    return ok != 0;
+}
+
+// nm_create's residency probe: a grid of the block kernel's shape (same workgroup size, same LDS request — the LDS alone admits one
+// workgroup per CU for every configuration, see the static_assert) that only takes the census.
+template <class C>
+__global__ void __launch_bounds__(C::BLOCK) nm_probe_kernel(const KParams p)
+{
+    static_assert(2 * C::LDS_BYTES > 160 * 1024, "the probe stands in for the block kernel only while LDS limits both to one workgroup per CU");
+    const int Q = p.cus, b = blockIdx.x;
+    int slot;
+    if ((p.nslots & 7) == 0) slot = (b & 7) + 8 * ((b >> 3) / Q); else slot = b / Q;
+    if (!residency_census<C>(p) && threadIdx.x == 0) atomicOr(&p.status[slot], (int)ST_NOT_RESIDENT);
+}
+
 // Phases of the per-replica state machine.  The block kernel is written so that eval() — by far the largest
 // piece of code and the only one whose cost matters — has exactly ONE call site; every move is split into the
 // part before its energy/force evaluation and the part after it.
@@ -1401,39 +1446,9 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
     const bool writer = (tid == 0 && qq == 0); // one workgroup of the cluster writes the replica's results
     const int N = p.N;
 
-    // Residency census (clusters only).  The workgroups of a cluster spin on one another, so the whole grid must be resident at
-    // once; HIP promises nothing of the kind, and a CU taken by another process, a CU mask or a second stream would leave part of
-    // the grid queued behind workgroups that wait for it.  Every workgroup signs in on one counter and waits (bounded: 200 us)
-    // until all have; whoever gives up sets an abort bit that also fails every later arrival, so the verdict is unanimous.  On
-    // failure nothing has been touched yet: the block leaves with ST_NOT_RESIDENT and the state in HBM is what it was.
-    if (Q > 1 && p.census) {
-        constexpr unsigned int ABORT = 0x80000000u;
-        int *flag = (int *)(nm_lds + C::OFF_RED);
-        if (tid == 0) {
-            const unsigned int want = gridDim.x;
-            atomicAdd(p.census, 1u);
-            const unsigned long long t0 = wall_clock64();
-            int ok = 0;
-            for (;;) {
-                const unsigned int v = __hip_atomic_load(p.census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (v == want) { ok = 1; break; }
-                if (v & ABORT) break;
-                if (wall_clock64() - t0 > 20000ull) { // 200 us of the 100 MHz clock
-                    ok = (atomicOr(p.census, ABORT) == want) ? 1 : 0;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(4);
-            }
-            *flag = ok;
-        }
-        __syncthreads();
-        const int ok = *flag;
-        __syncthreads(); // the slot is reused by the reductions
-        if (!ok) {
-            if (writer) p.status[slot] |= ST_NOT_RESIDENT;
-            return;
-        }
-        if (p.census_only) return;
+    if (Q > 1 && p.census && !residency_census<C>(p)) { // nothing has been touched yet
+        if (writer) p.status[slot] |= ST_NOT_RESIDENT;
+        return;
     }
 #ifdef NM_EXPERIMENT
     const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_w0 = wall_clock64();
