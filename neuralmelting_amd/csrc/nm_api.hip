@@ -119,6 +119,8 @@ void fill_params(const nm_ctx *c, KParams &p)
     p.prof = c->d_prof;
     p.cus = c->cus; p.xbuf = c->d_xbuf; p.launch_id = c->launch_id;
     p.census = c->cus > 1 ? c->d_census : nullptr;
+    p.plain_granules = 1;
+    if (const char *e = std::getenv("NM_PLAIN_GRANULES")) p.plain_granules = std::atoi(e);
     p.dbg = 0;
     p.tline = c->d_tline;
     if (const char *e = std::getenv("NM_DBG")) p.dbg = std::atoi(e);

@@ -272,6 +272,7 @@ struct Replica {
     __device__ __forceinline__ bool fresh() const { return (flags & F_FRESH) != 0; }
     __device__ __forceinline__ void set_fresh(bool b) { flags = b ? (flags | F_FRESH) : (flags & ~F_FRESH); }
     int status = 0;
+    bool same_xcd = false; // all workgroups of the cluster run on one XCD (read from the hardware, not assumed from blockIdx)
     const double *tape = nullptr;
     int tpos = 0, tlen = 0;
     double st_evals = 0.0, st_rebuilds = 0.0, st_eevals = 0.0, st_pairs = 0.0;
@@ -792,7 +793,10 @@ struct Replica {
         w.y = w.x ^ mg;
         // hipcc adds no wait states for an asm statement: a VMEM store of more than 8 bytes needs one before its data
         // registers may be overwritten (gfx9 hazard), hence the s_nop inside the string
-        if (NM_DBG(32)) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(g), "v"(w) : "memory"); // experiment: line stays in the XCD's L2
+        // one XCD (same_xcd, established at block start): a plain store leaves the line in that XCD's L2, where the peers' sc1
+        // loads (L1 bypassed) find it ~0.5 us sooner than after the write-through that sc1 stores force (they drop the line from
+        // L2, so the reader goes out to the fabric).  Across XCDs only the write-through form is visible at all.
+        if (same_xcd) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(g), "v"(w) : "memory");
         else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(g), "v"(w) : "memory");
     }
     // up to three granules per call, issued back to back and waited for once; `poisoned` is set when a granule carries the
@@ -1449,6 +1453,15 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
     if (Q > 1 && p.census && !residency_census<C>(p)) { // nothing has been touched yet
         if (writer) p.status[slot] |= ST_NOT_RESIDENT;
         return;
+    }
+    // Which XCD is this workgroup on?  HIP promises no placement; blockIdx % 8 is only the observed round-robin.  The members of a
+    // cluster exchange their XCC ids once per block (write-through granules, valid anywhere): sum and sum of squares over the Q
+    // members tell every member, identically, whether all ids are equal (Q sum(id^2) == (sum id)^2).
+    if (Q > 1 && p.plain_granules) {
+        const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu); // HW_REG_XCC_ID[3:0]
+        double s4[4] = { (double)xcc, (double)(xcc * xcc), 0.0, 0.0 };
+        R.template exchange_sums<4>(s4);
+        R.same_xcd = ((double)Q * s4[1] == s4[0] * s4[0]);
     }
 #ifdef NM_EXPERIMENT
     const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_w0 = wall_clock64();
