@@ -80,6 +80,16 @@ int nm_set_state(nm_ctx *ctx, int k0, int nk, const double *x, const double *v, 
                  const double *dxdvdt);
 int nm_get_state(nm_ctx *ctx, int k0, int nk, double *x, double *v, double *box, double *dxdvdt);
 
+/* init_samples (remcmc:394-456) for every local replica, for callers without the Python front end: fcc lattice in create_atoms
+   order, box edge statically relaxed to the row's pressure (what fix box/relax + minimize converge to for the perfect crystal),
+   uniform random displacement of amplitude dx*LAT, velocities zero, steps (dx, dv, TIMESTEP).  interpolate != 0: the volume
+   expansion of the -is branch (remcmc:409-419); follow with nm_run_md(ctx, 1024) for its dynamics.  natoms must be 4*sz^3.
+   Host code, once per run; the same states neuralmelting_amd/lattice.py produces. */
+int nm_init_lattice(nm_ctx *ctx, double dx, double dv, int interpolate);
+/* the same for ONE global slot without a context (no GPU involved): x[3*natoms], *box */
+int nm_lattice_state(int element, int sz, int np, int nt, const float *P, uint32_t seed, int gslot, double dx, int interpolate,
+                     double *x, double *box);
+
 /* thermo scalars carried by a state list (entries 3,4,5,6,8 of remcmc:432-433): th[nk][5] = temp, pe, ke, virial, vol.
    Needed when states come from a restart file and the first thing the reference does is replica_exchange (remcmc:966-968). */
 int nm_set_thermo(nm_ctx *ctx, int k0, int nk, const double *th);

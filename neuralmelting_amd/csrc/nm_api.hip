@@ -6,6 +6,7 @@
 #include "nm_distr.h"
 #include "nm_format.h"
 #include "nm_parse.h"
+#include "nm_lattice.h"
 #include "../../include/nm_distr.h"
 #include "../../include/nm_parse.h"
 
@@ -75,6 +76,7 @@ struct nm_ctx {
     int trace_on, trace_mod;
     int xtape_n;
     std::vector<double> h_et, h_pf, h_tq;
+    std::vector<float> h_P, h_T; // the context's own copy of the grids (cfg.P / cfg.T point here after nm_create)
     std::vector<EvPair> ev;
     int ev_next;
     int launches;
@@ -268,6 +270,8 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
 
     nm_ctx *c = new nm_ctx();
     c->cfg = *cfg;
+    c->h_P.assign(cfg->P, cfg->P + cfg->np); c->h_T.assign(cfg->T, cfg->T + cfg->nt);
+    c->cfg.P = c->h_P.data(); c->cfg.T = c->h_T.data();
     c->N = cfg->natoms;
     c->nslots = by_slots ? cfg->nslots : cfg->nrows * cfg->nt;
     c->slot0 = by_slots ? cfg->slot0 : cfg->row0 * cfg->nt;
@@ -515,6 +519,39 @@ int nm_set_state(nm_ctx *c, int k0, int nk, const double *x, const double *v, co
     if (dxdvdt) HIPCHK(c, hipMemcpyAsync(c->d_steps, hs, 3 * ns * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream)); // the staging area is reused by the next call
     return NM_OK;
+}
+
+int nm_lattice_state(int element, int sz, int np, int nt, const float *P, uint32_t seed, int gslot, double dx, int interpolate, double *x,
+                     double *box)
+{
+    if ((element != NM_EL_LJ && element != NM_EL_AL) || sz < 1 || np < 1 || nt < 1 || !P || gslot < 0 || gslot >= np * nt || !x || !box)
+        return fail(nullptr, NM_ERR_ARG, "nm_lattice_state: bad argument");
+    std::vector<double> frac;
+    lat::fcc_fractional(sz, frac);
+    const double b = lat::relax_box(element, sz, (double)P[gslot / nt]);
+    lat::init_state(element, sz, b, seed, gslot, gslot % nt, nt, dx, interpolate, frac, x, box);
+    return NM_OK;
+}
+
+int nm_init_lattice(nm_ctx *c, double dx, double dv, int interpolate)
+{
+    if (!c) return NM_ERR_ARG;
+    int sz = 1;
+    while (4 * sz * sz * sz < c->N) ++sz;
+    if (4 * sz * sz * sz != c->N) return fail(c, NM_ERR_ARG, "nm_init_lattice: natoms is not 4*sz^3 (fcc)");
+    const int ns = c->nslots, nt = c->cfg.nt;
+    const size_t n3 = (size_t)3 * c->N;
+    std::vector<double> frac, x((size_t)ns * n3), v((size_t)ns * n3, 0.0), box((size_t)ns), d((size_t)3 * ns);
+    lat::fcc_fractional(sz, frac);
+    double brow = 0.0;
+    int row = -1;
+    for (int k = 0; k < ns; ++k) {
+        const int g = c->slot0 + k, i = g / nt, j = g % nt;
+        if (i != row) { brow = lat::relax_box(c->cfg.element, sz, (double)c->cfg.P[i]); row = i; }
+        lat::init_state(c->cfg.element, sz, brow, c->cfg.seed, g, j, nt, dx, interpolate, frac, x.data() + (size_t)k * n3, &box[k]);
+        d[3 * k] = dx; d[3 * k + 1] = dv; d[3 * k + 2] = 0.00390625; // TIMESTEP, remcmc:891-893 (lj and metal)
+    }
+    return nm_set_state(c, 0, ns, x.data(), v.data(), box.data(), d.data());
 }
 
 int nm_set_thermo(nm_ctx *c, int k0, int nk, const double *th)

@@ -105,6 +105,10 @@ class Engine:
         self._chk(self.lib.nm_get_state(self.h, k0, nk, _dp(x), _dp(v) if velocities else None, _dp(box), _dp(d)))
         return x, v, box, d
 
+    def init_lattice(self, dx=0.03125, dv=0.03125, interpolate=False):
+        """init_samples (remcmc:394-456) through the C-ABI: the states lattice.init_states builds, without the Python front end"""
+        self._chk(self.lib.nm_init_lattice(self.h, float(dx), float(dv), int(bool(interpolate))))
+
     def set_thermo(self, th, k0=0, nk=None):
         """th[nk][5] = temp, pe, ke, virial, vol (state-list entries 3,4,5,6,8): for restarts"""
         nk = self.nslots - k0 if nk is None else nk
