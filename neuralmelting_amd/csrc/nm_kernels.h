@@ -445,13 +445,26 @@ struct Replica {
         else return ((size_t)(r / C::CH) * NMAX + i) * C::CH + (r % C::CH);
     }
 
+    // The candidate test runs in fp32 on a float copy of the positions: VALU issue is what bounds the build (N candidates per row,
+    // ~25 arithmetic instructions each) and fp32 issues at twice the fp64 rate.  The copy lives in the force array, which is dead
+    // here: every caller of rebuild() is about to run the pair loop that rewrites it.  The radius is enlarged by the worst-case fp32
+    // error (positions rounded to 2^-24 relative of at most 1.5 L, difference, image shift, square: < 16 L 2^-24 in r), so the
+    // list is a superset of the exact one: the extra entries lie beyond rc + skin and are masked by the pair loop's exact fp64
+    // cutoff test, contributing an exact zero in the same place of the sum.  (The list itself is not observable in any result.)
     __device__ void rebuild()
     {
         const int lane = tid & 63, wv = tid >> 6;
-        const double invL = 1.0 / L, rl = p.rc + p.skin, rl2 = rl * rl;
+        float *xf = (float *)(nm_lds + C::OFF_FRC), *yf = xf + NMAX, *zf = yf + NMAX;
+        static_assert(3 * sizeof(float) <= 3 * sizeof(double), "");
+        for (int i = tid; i < N; i += BLOCK) { xf[i] = (float)px[i]; yf[i] = (float)py[i]; zf[i] = (float)pz[i]; }
+        set_fresh(false); // the forces are gone
+        __syncthreads();
+        const float Lf = (float)L, invLf = 1.0f / Lf;
+        const double rl = p.rc + p.skin + 16.0 * L * 5.9604644775390625e-8;
+        const float rl2 = (float)(rl * rl * (1.0 + 4.0e-6));
         int ovf = 0;
         for (int i = a0 + wv; i < a1; i += NW) { // this workgroup's rows of the list
-            const double xi = px[i], yi = py[i], zi = pz[i];
+            const float xi = xf[i], yi = yf[i], zi = zf[i];
             int base = 0;
             for (int j0 = 0; j0 < N; j0 += 256) { // four 64-candidate blocks in flight: the distance tests are independent
                 bool in[4];
@@ -461,8 +474,8 @@ struct Replica {
                     const int j = j0 + 64 * b + lane;
                     in[b] = false;
                     if (j < N && j != i) {
-                        double dx = xi - px[j], dy = yi - py[j], dz = zi - pz[j];
-                        dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
+                        float dx = xi - xf[j], dy = yi - yf[j], dz = zi - zf[j];
+                        dx -= Lf * rintf(dx * invLf); dy -= Lf * rintf(dy * invLf); dz -= Lf * rintf(dz * invLf);
                         in[b] = (dx * dx + dy * dy + dz * dz) < rl2;
                     }
                 }
