@@ -445,30 +445,166 @@ struct Replica {
         else return ((size_t)(r / C::CH) * NMAX + i) * C::CH + (r % C::CH);
     }
 
-    // The candidate test runs in fp32 on a float copy of the positions: VALU issue is what bounds the build (N candidates per row,
-    // ~25 arithmetic instructions each) and fp32 issues at twice the fp64 rate.  The copy lives in the force array, which is dead
-    // here: every caller of rebuild() is about to run the pair loop that rewrites it.  The radius is enlarged by the worst-case fp32
-    // error (positions rounded to 2^-24 relative of at most 1.5 L, difference, image shift, square: < 16 L 2^-24 in r), so the
-    // list is a superset of the exact one: the extra entries lie beyond rc + skin and are masked by the pair loop's exact fp64
-    // cutoff test, contributing an exact zero in the same place of the sum.  (The list itself is not observable in any result.)
+    // ascending bitonic sort of one value per lane across the 64 lanes of a wave
+    __device__ __forceinline__ unsigned int wave_sort64(unsigned int v) const
+    {
+        const int lane = tid & 63;
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const unsigned int o = (unsigned int)__shfl_xor((int)v, j, 64);
+                const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+                v = (lower == up) ? (v < o ? v : o) : (v < o ? o : v);
+            }
+        return v;
+    }
+
+    // one 64-candidate step of a row build: lanes that hold a candidate in range append it to row i in lane order
+    // (lists that live in HBM/L2 are staged per row in `rowbuf` (LDS) and written out by flush_row as whole 8-byte chunks: appended
+    // directly, every entry was a 2-byte store into a line of its own)
+    __device__ __forceinline__ void append_step(int i, bool in, int j, int &base, IdxT *rowbuf)
+    {
+        const unsigned long long m = __ballot(in);
+        if (in) {
+            const int r = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (r < MAXNB) {
+                if constexpr (C::LIST_LDS) nbr[nbr_at(r, i)] = (IdxT)j;
+                else rowbuf[r] = (IdxT)j;
+            }
+        }
+        base += __popcll(m);
+    }
+    __device__ __forceinline__ void flush_row(int i, int count, const IdxT *rowbuf)
+    {
+        if constexpr (!C::LIST_LDS) {
+            static_assert(C::CH * sizeof(IdxT) == 8, "a chunk is one 8-byte word");
+            unsigned long long *g = (unsigned long long *)nbr.ptr();
+            const unsigned long long *r8 = (const unsigned long long *)rowbuf;
+            const int nch = (count + C::CH - 1) / C::CH;
+            for (int ch = tid & 63; ch < nch; ch += 64) g[(size_t)ch * NMAX + i] = r8[ch]; // entries past `count` in the last chunk: never read
+        }
+    }
+
+    // Verlet-list rebuild.
+    // * The candidate test runs in fp32 on a float copy of the positions: VALU issue bounds the build and fp32 issues at twice the
+    //   fp64 rate.  The copy lives in the force array, which is dead here: every caller of rebuild() is about to run the pair loop
+    //   that rewrites it.  The radius is enlarged by the worst-case fp32 error (positions rounded to 2^-24 relative of at most
+    //   1.5 L, difference, image shift, square: < 16 L 2^-24 in r), so the list is a superset of the exact one: the extra entries lie
+    //   beyond rc + skin and are masked by the pair loop's exact fp64 cutoff test, contributing an exact zero in the same place
+    //   of the sum.  (The list itself is not observable in any result.)
+    // * Systems of more than 256 atoms bin the atoms into columns first: nc x nc cells in (y, z) of edge >= (rc + skin) / 2, all x.
+    //   A row then tests the 5 x 5 columns around its atom (39 % of the atoms at nc = 8) instead of all: at equilibrium the
+    //   brute-force build was ~70 % of the 8^3 kernel's time (one to two rebuilds per move once HMC accepts, N^2 tests each).
+    //   Columns are filled with LDS atomics and then sorted by atom index inside each column (bitonic, one wave per column), so
+    //   the structure — and with it every list row and every summation order — is a function of the positions alone.  Rows come
+    //   out ordered by (column, index) instead of by index; boxes with fewer than 7 columns per edge (there the stencil is most of
+    //   the box and the binning measured as pure overhead: -16 % at 6^3, -29 % at 5^3), or a column of more than 64 atoms, fall
+    //   back to testing all atoms.
     __device__ void rebuild()
     {
         const int lane = tid & 63, wv = tid >> 6;
         float *xf = (float *)(nm_lds + C::OFF_FRC), *yf = xf + NMAX, *zf = yf + NMAX;
-        static_assert(3 * sizeof(float) <= 3 * sizeof(double), "");
         for (int i = tid; i < N; i += BLOCK) { xf[i] = (float)px[i]; yf[i] = (float)py[i]; zf[i] = (float)pz[i]; }
         set_fresh(false); // the forces are gone
-        __syncthreads();
         const float Lf = (float)L, invLf = 1.0f / Lf;
         const double rl = p.rc + p.skin + 16.0 * L * 5.9604644775390625e-8;
         const float rl2 = (float)(rl * rl * (1.0 + 4.0e-6));
         int ovf = 0;
+        bool columns = false;
+        int nc = 0;
+        unsigned short *sorted = (unsigned short *)(zf + NMAX), *colof = sorted + NMAX;
+        int *ccnt = (int *)(colof + NMAX), *cstart = ccnt + 64; // 64 counters, 65 offsets
+        IdxT *rowbuf = (IdxT *)(cstart + 66) + (size_t)wv * MAXNB; // one row per wave (lists outside LDS)
+        static_assert((size_t)3 * NMAX * sizeof(float) + (size_t)2 * NMAX * sizeof(unsigned short) + 130 * sizeof(int)
+                              + (C::LIST_LDS ? 0 : (size_t)NW * MAXNB * sizeof(IdxT))
+                          <= (size_t)3 * NMAX * sizeof(double), "the rebuild's scratch must fit the force array");
+        if constexpr (NMAX > 256) {
+            nc = (int)(2.0 * L / rl);
+            nc = nc > 8 ? 8 : nc;
+            if (nc >= 7 && p.rebuild_columns) { // (5 or 6 columns per edge: the 5 x 5 stencil is all or most of them, the binning pure overhead)
+                const int ncol = nc * nc;
+                if (tid < 64) ccnt[tid] = 0;
+                __syncthreads(); // float copy and zeroed counters
+                constexpr int PER = (NMAX + BLOCK - 1) / BLOCK;
+                int mycol[PER], myslot[PER];
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    const int i = tid + k * BLOCK;
+                    mycol[k] = 0; myslot[k] = 0;
+                    if (i < N) {
+                        float fy = yf[i] * invLf, fz = zf[i] * invLf;
+                        fy -= floorf(fy); fz -= floorf(fz);
+                        int cy = (int)(fy * (float)nc), cz = (int)(fz * (float)nc);
+                        cy = cy >= nc ? nc - 1 : cy; cz = cz >= nc ? nc - 1 : cz;
+                        mycol[k] = cz * nc + cy;
+                        colof[i] = (unsigned short)mycol[k];
+                        myslot[k] = atomicAdd(&ccnt[mycol[k]], 1);
+                    }
+                }
+                __syncthreads();
+                { // offsets: every wave scans the 64 counters, wave 0 publishes
+                    const int c = lane < ncol ? ccnt[lane] : 0;
+                    int incl = c;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+                    if (wv == 0) { cstart[lane] = incl - c; if (lane == 63) cstart[64] = incl; }
+                    if (c > 64) ovf = 2; // a column too long for the in-wave sort: fall back
+                }
+                const bool too_long = block_any<NW, NVMAX>(ovf != 0, red, parity);
+                ovf = 0;
+                if (!too_long) {
+#pragma unroll
+                    for (int k = 0; k < PER; ++k) {
+                        const int i = tid + k * BLOCK;
+                        if (i < N) sorted[cstart[mycol[k]] + myslot[k]] = (unsigned short)i;
+                    }
+                    __syncthreads();
+                    for (int c = wv; c < ncol; c += NW) { // canonical order inside each column
+                        const int s0 = cstart[c], n = cstart[c + 1] - s0;
+                        unsigned int v = lane < n ? (unsigned int)sorted[s0 + lane] : 0xFFFFu;
+                        v = wave_sort64(v);
+                        if (lane < n) sorted[s0 + lane] = (unsigned short)v;
+                    }
+                    columns = true;
+                }
+            }
+        }
+        __syncthreads(); // float copy (and columns) complete
         for (int i = a0 + wv; i < a1; i += NW) { // this workgroup's rows of the list
             const float xi = xf[i], yi = yf[i], zi = zf[i];
             int base = 0;
-            for (int j0 = 0; j0 < N; j0 += 256) { // four 64-candidate blocks in flight: the distance tests are independent
+            if (NMAX > 256 && columns) {
+                const int col = colof[i], cz = col / nc, cy = col - cz * nc;
+                for (int dz = -2; dz <= 2; ++dz) {
+                    int z2 = cz + dz; z2 += z2 < 0 ? nc : 0; z2 -= z2 >= nc ? nc : 0;
+                    // columns cy-2 .. cy+2 of row z2: one run of `sorted`, or two when the range wraps
+                    const int lo = cy - 2, hi = cy + 2;
+                    for (int part = 0; part < 2; ++part) {
+                        int c0, c1; // column range [c0, c1] of this part
+                        if (part == 0) { c0 = lo < 0 ? 0 : lo; c1 = hi >= nc ? nc - 1 : hi; }
+                        else if (lo < 0) { c0 = lo + nc; c1 = nc - 1; }
+                        else if (hi >= nc) { c0 = 0; c1 = hi - nc; }
+                        else break;
+                        const int t1 = __builtin_amdgcn_readfirstlane(cstart[z2 * nc + c1 + 1]);
+                        // (four blocks in flight per run, as the all-atoms loop below has, measured 2x SLOWER here: the 8^3 kernel
+                        // is short of registers and the staged indices went to scratch)
+                        for (int t = __builtin_amdgcn_readfirstlane(cstart[z2 * nc + c0]) + lane; __ballot(t < t1) != 0ull; t += 64) {
+                            bool in = false;
+                            int j = 0;
+                            if (t < t1) {
+                                j = sorted[t];
+                                float dx = xi - xf[j], dy = yi - yf[j], dzz = zi - zf[j];
+                                dx -= Lf * rintf(dx * invLf); dy -= Lf * rintf(dy * invLf); dzz -= Lf * rintf(dzz * invLf);
+                                in = j != i && (dx * dx + dy * dy + dzz * dzz) < rl2;
+                            }
+                            append_step(i, in, j, base, rowbuf);
+                        }
+                    }
+                }
+            } else
+            for (int j0 = 0; j0 < N; j0 += 256) { // all atoms; four 64-candidate blocks in flight: the distance tests are independent
                 bool in[4];
-                unsigned long long m[4];
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int j = j0 + 64 * b + lane;
@@ -480,19 +616,11 @@ struct Replica {
                     }
                 }
 #pragma unroll
-                for (int b = 0; b < 4; ++b) m[b] = __ballot(in[b]);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    if (in[b]) {
-                        const int r = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m[b] >> 32),
-                                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)m[b], 0u));
-                        if (r < MAXNB) nbr[nbr_at(r, i)] = (IdxT)(j0 + 64 * b + lane);
-                    }
-                    base += __popcll(m[b]);
-                }
+                for (int b = 0; b < 4; ++b) append_step(i, in[b], j0 + 64 * b + lane, base, rowbuf);
             }
             if (base > MAXNB) { ovf = 1; base = MAXNB; }
             if (lane == 0) cnt[i] = (unsigned short)base;
+            flush_row(i, base, rowbuf);
         }
         for (int i = tid; i < N; i += BLOCK) { x0[i] = px[i]; y0[i] = py[i]; z0[i] = pz[i]; }
         L0 = L;
