@@ -122,8 +122,6 @@ void fill_params(const nm_ctx *c, KParams &p)
     p.cus = c->cus; p.xbuf = c->d_xbuf; p.launch_id = c->launch_id;
     p.census = c->cus > 1 ? c->d_census : nullptr;
     p.plain_granules = 1;
-    p.rebuild_columns = 1;
-    if (const char *e = std::getenv("NM_REBUILD_COLUMNS")) p.rebuild_columns = std::atoi(e);
     if (const char *e = std::getenv("NM_PLAIN_GRANULES")) p.plain_granules = std::atoi(e);
     p.dbg = 0;
     p.tline = c->d_tline;

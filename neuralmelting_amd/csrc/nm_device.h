@@ -50,7 +50,6 @@ struct KParams {
     unsigned long long *tline;     // experiment build only: 100 MHz timestamps of slot 0's evaluations [q][wave][eval][8]
     double *xbuf;                  // [slot][2][XBUF_DOUBLES]: force slices + partial sums exchanged inside a cluster
     uint32_t launch_id;            // distinguishes the granules of successive launches
-    int rebuild_columns;           // 1: rebuilds of systems > 256 atoms bin the atoms into (y, z) columns first; 0: test all atoms (A/B switch)
     int plain_granules;            // 1: clusters found to sit on one XCD hand over through that XCD's L2 (plain stores); 0: always write-through
     unsigned int *census;          // cluster launches: arrival counter of the grid's workgroups (zeroed before the launch)
 };

@@ -445,45 +445,15 @@ struct Replica {
         else return ((size_t)(r / C::CH) * NMAX + i) * C::CH + (r % C::CH);
     }
 
-    // ascending bitonic sort of one value per lane across the 64 lanes of a wave
-    __device__ __forceinline__ unsigned int wave_sort64(unsigned int v) const
-    {
-        const int lane = tid & 63;
-#pragma unroll
-        for (int k = 2; k <= 64; k <<= 1)
-#pragma unroll
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                const unsigned int o = (unsigned int)__shfl_xor((int)v, j, 64);
-                const bool up = (lane & k) == 0, lower = (lane & j) == 0;
-                v = (lower == up) ? (v < o ? v : o) : (v < o ? o : v);
-            }
-        return v;
-    }
-
-    // one 64-candidate step of a row build: lanes that hold a candidate in range append it to row i in lane order
-    // (lists that live in HBM/L2 are staged per row in `rowbuf` (LDS) and written out by flush_row as whole 8-byte chunks: appended
-    // directly, every entry was a 2-byte store into a line of its own)
-    __device__ __forceinline__ void append_step(int i, bool in, int j, int &base, IdxT *rowbuf)
+    // one 64-candidate step of a wave-per-atom row build: lanes that hold a candidate in range append it to row i in lane order
+    __device__ __forceinline__ void append_step(int i, bool in, int j, int &base)
     {
         const unsigned long long m = __ballot(in);
         if (in) {
             const int r = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (r < MAXNB) {
-                if constexpr (C::LIST_LDS) nbr[nbr_at(r, i)] = (IdxT)j;
-                else rowbuf[r] = (IdxT)j;
-            }
+            if (r < MAXNB) nbr[nbr_at(r, i)] = (IdxT)j;
         }
         base += __popcll(m);
-    }
-    __device__ __forceinline__ void flush_row(int i, int count, const IdxT *rowbuf)
-    {
-        if constexpr (!C::LIST_LDS) {
-            static_assert(C::CH * sizeof(IdxT) == 8, "a chunk is one 8-byte word");
-            unsigned long long *g = (unsigned long long *)nbr.ptr();
-            const unsigned long long *r8 = (const unsigned long long *)rowbuf;
-            const int nch = (count + C::CH - 1) / C::CH;
-            for (int ch = tid & 63; ch < nch; ch += 64) g[(size_t)ch * NMAX + i] = r8[ch]; // entries past `count` in the last chunk: never read
-        }
     }
 
     // Verlet-list rebuild.
@@ -493,14 +463,15 @@ struct Replica {
     //   1.5 L, difference, image shift, square: < 16 L 2^-24 in r), so the list is a superset of the exact one: the extra entries lie
     //   beyond rc + skin and are masked by the pair loop's exact fp64 cutoff test, contributing an exact zero in the same place
     //   of the sum.  (The list itself is not observable in any result.)
-    // * Systems of more than 256 atoms bin the atoms into columns first: nc x nc cells in (y, z) of edge >= (rc + skin) / 2, all x.
-    //   A row then tests the 5 x 5 columns around its atom (39 % of the atoms at nc = 8) instead of all: at equilibrium the
-    //   brute-force build was ~70 % of the 8^3 kernel's time (one to two rebuilds per move once HMC accepts, N^2 tests each).
-    //   Columns are filled with LDS atomics and then sorted by atom index inside each column (bitonic, one wave per column), so
-    //   the structure — and with it every list row and every summation order — is a function of the positions alone.  Rows come
-    //   out ordered by (column, index) instead of by index; boxes with fewer than 7 columns per edge (there the stencil is most of
-    //   the box and the binning measured as pure overhead: -16 % at 6^3, -29 % at 5^3), or a column of more than 64 atoms, fall
-    //   back to testing all atoms.
+    // * Lists in LDS (N <= 256, and the 6^3 system at 8 workgroups per replica): one WAVE per row, 64 candidates per step, ballot
+    //   compaction keeps the row sorted by j.
+    // * Lists in HBM/L2 (one thread per atom in the pair loop): one THREAD per row.  All lanes of a wave test the same candidate
+    //   j at the same time, so its coordinates are three broadcast LDS reads, there is no cross-lane step at all, and the loop over
+    //   j unrolls into independent tests; a thread packs four indices into the 8-byte chunk the pair loop reads and stores it
+    //   whole (lanes = consecutive atoms = consecutive words of the [chunk][atom] layout).  The wave-per-row form took ~0.45 ms per
+    //   rebuild of a 2048-atom replica — bound by its dependent chain index read -> gathers -> ballot, 32 times per row — which
+    //   was ~70 % of the 8^3 kernel once the chains have equilibrated (one to two rebuilds per move when HMC accepts); a (y, z)
+    //   column binning with a 5 x 5 stencil in front of it gained only 1.3x and is gone again.
     __device__ void rebuild()
     {
         const int lane = tid & 63, wv = tid >> 6;
@@ -511,116 +482,77 @@ struct Replica {
         const double rl = p.rc + p.skin + 16.0 * L * 5.9604644775390625e-8;
         const float rl2 = (float)(rl * rl * (1.0 + 4.0e-6));
         int ovf = 0;
-        bool columns = false;
-        int nc = 0;
-        unsigned short *sorted = (unsigned short *)(zf + NMAX), *colof = sorted + NMAX;
-        int *ccnt = (int *)(colof + NMAX), *cstart = ccnt + 64; // 64 counters, 65 offsets
-        IdxT *rowbuf = (IdxT *)(cstart + 66) + (size_t)wv * MAXNB; // one row per wave (lists outside LDS)
-        static_assert((size_t)3 * NMAX * sizeof(float) + (size_t)2 * NMAX * sizeof(unsigned short) + 130 * sizeof(int)
-                              + (C::LIST_LDS ? 0 : (size_t)NW * MAXNB * sizeof(IdxT))
-                          <= (size_t)3 * NMAX * sizeof(double), "the rebuild's scratch must fit the force array");
-        if constexpr (NMAX > 256) {
-            nc = (int)(2.0 * L / rl);
-            nc = nc > 8 ? 8 : nc;
-            if (nc >= 7 && p.rebuild_columns) { // (5 or 6 columns per edge: the 5 x 5 stencil is all or most of them, the binning pure overhead)
-                const int ncol = nc * nc;
-                if (tid < 64) ccnt[tid] = 0;
-                __syncthreads(); // float copy and zeroed counters
-                constexpr int PER = (NMAX + BLOCK - 1) / BLOCK;
-                int mycol[PER], myslot[PER];
+        __syncthreads(); // the float copy is complete
+        if constexpr (C::LIST_LDS) {
+            for (int i = a0 + wv; i < a1; i += NW) { // this workgroup's rows of the list
+                const float xi = xf[i], yi = yf[i], zi = zf[i];
+                int base = 0;
+                for (int j0 = 0; j0 < N; j0 += 256) { // four 64-candidate blocks in flight: the distance tests are independent
+                    bool in[4];
 #pragma unroll
-                for (int k = 0; k < PER; ++k) {
-                    const int i = tid + k * BLOCK;
-                    mycol[k] = 0; myslot[k] = 0;
-                    if (i < N) {
-                        float fy = yf[i] * invLf, fz = zf[i] * invLf;
-                        fy -= floorf(fy); fz -= floorf(fz);
-                        int cy = (int)(fy * (float)nc), cz = (int)(fz * (float)nc);
-                        cy = cy >= nc ? nc - 1 : cy; cz = cz >= nc ? nc - 1 : cz;
-                        mycol[k] = cz * nc + cy;
-                        colof[i] = (unsigned short)mycol[k];
-                        myslot[k] = atomicAdd(&ccnt[mycol[k]], 1);
+                    for (int b = 0; b < 4; ++b) {
+                        const int j = j0 + 64 * b + lane;
+                        in[b] = false;
+                        if (j < N && j != i) {
+                            float dx = xi - xf[j], dy = yi - yf[j], dz = zi - zf[j];
+                            dx -= Lf * rintf(dx * invLf); dy -= Lf * rintf(dy * invLf); dz -= Lf * rintf(dz * invLf);
+                            in[b] = (dx * dx + dy * dy + dz * dz) < rl2;
+                        }
                     }
-                }
-                __syncthreads();
-                { // offsets: every wave scans the 64 counters, wave 0 publishes
-                    const int c = lane < ncol ? ccnt[lane] : 0;
-                    int incl = c;
 #pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-                    if (wv == 0) { cstart[lane] = incl - c; if (lane == 63) cstart[64] = incl; }
-                    if (c > 64) ovf = 2; // a column too long for the in-wave sort: fall back
+                    for (int b = 0; b < 4; ++b) append_step(i, in[b], j0 + 64 * b + lane, base);
                 }
-                const bool too_long = block_any<NW, NVMAX>(ovf != 0, red, parity);
-                ovf = 0;
-                if (!too_long) {
-#pragma unroll
-                    for (int k = 0; k < PER; ++k) {
-                        const int i = tid + k * BLOCK;
-                        if (i < N) sorted[cstart[mycol[k]] + myslot[k]] = (unsigned short)i;
-                    }
-                    __syncthreads();
-                    for (int c = wv; c < ncol; c += NW) { // canonical order inside each column
-                        const int s0 = cstart[c], n = cstart[c + 1] - s0;
-                        unsigned int v = lane < n ? (unsigned int)sorted[s0 + lane] : 0xFFFFu;
-                        v = wave_sort64(v);
-                        if (lane < n) sorted[s0 + lane] = (unsigned short)v;
-                    }
-                    columns = true;
-                }
+                if (base > MAXNB) { ovf = 1; base = MAXNB; }
+                if (lane == 0) cnt[i] = (unsigned short)base;
             }
-        }
-        __syncthreads(); // float copy (and columns) complete
-        for (int i = a0 + wv; i < a1; i += NW) { // this workgroup's rows of the list
-            const float xi = xf[i], yi = yf[i], zi = zf[i];
-            int base = 0;
-            if (NMAX > 256 && columns) {
-                const int col = colof[i], cz = col / nc, cy = col - cz * nc;
-                for (int dz = -2; dz <= 2; ++dz) {
-                    int z2 = cz + dz; z2 += z2 < 0 ? nc : 0; z2 -= z2 >= nc ? nc : 0;
-                    // columns cy-2 .. cy+2 of row z2: one run of `sorted`, or two when the range wraps
-                    const int lo = cy - 2, hi = cy + 2;
-                    for (int part = 0; part < 2; ++part) {
-                        int c0, c1; // column range [c0, c1] of this part
-                        if (part == 0) { c0 = lo < 0 ? 0 : lo; c1 = hi >= nc ? nc - 1 : hi; }
-                        else if (lo < 0) { c0 = lo + nc; c1 = nc - 1; }
-                        else if (hi >= nc) { c0 = 0; c1 = hi - nc; }
-                        else break;
-                        const int t1 = __builtin_amdgcn_readfirstlane(cstart[z2 * nc + c1 + 1]);
-                        // (four blocks in flight per run, as the all-atoms loop below has, measured 2x SLOWER here: the 8^3 kernel
-                        // is short of registers and the staged indices went to scratch)
-                        for (int t = __builtin_amdgcn_readfirstlane(cstart[z2 * nc + c0]) + lane; __ballot(t < t1) != 0ull; t += 64) {
-                            bool in = false;
-                            int j = 0;
-                            if (t < t1) {
-                                j = sorted[t];
-                                float dx = xi - xf[j], dy = yi - yf[j], dzz = zi - zf[j];
-                                dx -= Lf * rintf(dx * invLf); dy -= Lf * rintf(dy * invLf); dzz -= Lf * rintf(dzz * invLf);
-                                in = j != i && (dx * dx + dy * dy + dzz * dzz) < rl2;
+        } else {
+            static_assert(C::CH == 4 && sizeof(IdxT) == 2 && MAXNB % 4 == 0, "four 16-bit indices per 8-byte chunk");
+            unsigned long long *g = (unsigned long long *)nbr.ptr();
+            for (int i0 = a0; i0 < a1; i0 += BLOCK) { // one thread per row; uniform trip count: every lane of a wave must take part
+                const bool active = i0 + tid < a1;    // in the candidate loads below (v_readlane reads lanes whatever their exec bit)
+                const int i = active ? i0 + tid : a1 - 1;
+                const float xi = xf[i], yi = yf[i], zi = zf[i];
+                int c = 0;
+                unsigned int lo = 0u, hi = 0u; // the chunk being filled: four 16-bit indices
+                for (int j0 = 0; j0 < N; j0 += 64) {
+                    // 64 candidates per block.  Each lane fetches ONE of them (a coalesced read), and the block is then walked
+                    // with v_readlane: a candidate's coordinates reach all lanes as scalar operands, no LDS access and no load
+                    // latency per candidate.  The tests are branch-free, one bit each: appending inside this loop would put a
+                    // divergent branch behind every test (some lane of the wave is in range of nearly every candidate; measured
+                    // 5x the arithmetic).
+                    const int jl = j0 + lane < N ? j0 + lane : N - 1;
+                    const int cxb = __float_as_int(xf[jl]), cyb = __float_as_int(yf[jl]), czb = __float_as_int(zf[jl]);
+                    unsigned int m0 = 0u, m1 = 0u;
+#pragma unroll
+                    for (int b = 0; b < 64; ++b) {
+                        const float cx = __int_as_float(__builtin_amdgcn_readlane(cxb, b)), cy = __int_as_float(__builtin_amdgcn_readlane(cyb, b)),
+                                    cz = __int_as_float(__builtin_amdgcn_readlane(czb, b));
+                        float dx = xi - cx, dy = yi - cy, dz = zi - cz;
+                        dx -= Lf * rintf(dx * invLf); dy -= Lf * rintf(dy * invLf); dz -= Lf * rintf(dz * invLf);
+                        const unsigned int bit = ((dx * dx + dy * dy + dz * dz) < rl2 && j0 + b < N) ? (1u << (b & 31)) : 0u;
+                        if (b < 32) m0 |= bit; else m1 |= bit;
+                    }
+                    if ((unsigned int)(i - j0) < 32u) m0 &= ~(1u << (i - j0)); // not the atom itself
+                    else if ((unsigned int)(i - j0) < 64u) m1 &= ~(1u << (i - j0 - 32));
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        unsigned int m = half ? m1 : m0;
+                        while (m) { // a few bits per thread and block
+                            const unsigned int j = (unsigned int)(j0 + 32 * half + __builtin_ctz(m));
+                            m &= m - 1u;
+                            if (c < MAXNB) {
+                                const unsigned int v = j << (16 * (c & 1));
+                                if (c & 2) hi |= v; else lo |= v;
+                                if ((c & 3) == 3) { if (active) g[(size_t)(c >> 2) * NMAX + i] = ((unsigned long long)hi << 32) | lo; lo = hi = 0u; }
                             }
-                            append_step(i, in, j, base, rowbuf);
+                            ++c;
                         }
                     }
                 }
-            } else
-            for (int j0 = 0; j0 < N; j0 += 256) { // all atoms; four 64-candidate blocks in flight: the distance tests are independent
-                bool in[4];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int j = j0 + 64 * b + lane;
-                    in[b] = false;
-                    if (j < N && j != i) {
-                        float dx = xi - xf[j], dy = yi - yf[j], dz = zi - zf[j];
-                        dx -= Lf * rintf(dx * invLf); dy -= Lf * rintf(dy * invLf); dz -= Lf * rintf(dz * invLf);
-                        in[b] = (dx * dx + dy * dy + dz * dz) < rl2;
-                    }
-                }
-#pragma unroll
-                for (int b = 0; b < 4; ++b) append_step(i, in[b], j0 + 64 * b + lane, base, rowbuf);
+                if (active && c < MAXNB && (c & 3)) g[(size_t)(c >> 2) * NMAX + i] = ((unsigned long long)hi << 32) | lo; // the last, partial chunk
+                if (c > MAXNB) { ovf = 1; c = MAXNB; }
+                if (active) cnt[i] = (unsigned short)c;
             }
-            if (base > MAXNB) { ovf = 1; base = MAXNB; }
-            if (lane == 0) cnt[i] = (unsigned short)base;
-            flush_row(i, base, rowbuf);
         }
         for (int i = tid; i < N; i += BLOCK) { x0[i] = px[i]; y0[i] = py[i]; z0[i] = pz[i]; }
         L0 = L;

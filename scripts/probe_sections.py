@@ -11,9 +11,10 @@ NAMES = ['eval:entry barrier', 'eval:list check', 'eval:rebuild', 'eval:pair loo
          'post:init', 'post:bulk', 'post:vmc', 'post:hmc start', 'post:hmc step', 'pre:bulk', 'pre:vmc', 'pre:hmc', 'iter pmc', 'eval:cluster exchange', '-']
 
 def main(sz=4, rows=8, tn=8, mod=128, cycles=3, warm=6):
-    P = np.linspace(1, 8, rows, dtype=np.float32); T = np.linspace(.25, 2.5, tn, dtype=np.float32)
-    x, v, box, d = lattice.init_states(sz, P, T, 0.03125, 0.03125)
-    e = nm.Engine(4 * sz ** 3, P, T)
+    npn = int(os.environ.get('NP_ALL', rows))
+    P = np.linspace(1, 8, npn, dtype=np.float32); T = np.linspace(.25, 2.5, tn, dtype=np.float32)
+    x, v, box, d = lattice.init_states(sz, P, T, 0.03125, 0.03125, row0=0, nrows=rows)
+    e = nm.Engine(4 * sz ** 3, P, T, row0=0, nrows=rows)
     e.set_state(x, v, box, d)
     L = _lib.load()
     L.nm_prof_get.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -41,4 +42,6 @@ def main(sz=4, rows=8, tn=8, mod=128, cycles=3, warm=6):
     e.close()
 
 if __name__ == '__main__':
-    main()
+    # python scripts/probe_sections.py [sz rows tn mod cycles warm]
+    a = [int(v) for v in sys.argv[1:]]
+    main(*a)
