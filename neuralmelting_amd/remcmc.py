@@ -10,6 +10,7 @@ torch.distributed.run (one process per GPU).
 """
 import argparse
 import os
+import sys
 import time
 
 import numpy as np
@@ -450,12 +451,26 @@ def main(argv=None):
             torch.cuda.set_device(local)
         dist.init_process_group(backend)
     run = Run(argv, rank=rank, world=world, device=local)
+    run_guarded(run)
+
+
+def run_guarded(run):
+    """run.main() of one rank.  An error on one rank of several must not leave the others waiting in a barrier or a collective for
+    ever: the failing rank leaves at once with a failure code and the launcher (torch.distributed.run) ends the rest."""
     try:
+        if os.environ.get('NM_TEST_FAIL_RANK') == str(run.rank):   # test hook: tests/test_multiproc.py
+            raise RuntimeError('injected failure on rank %d' % run.rank)
         run.main()
-    finally:
-        if world > 1:
-            import torch.distributed as dist
-            dist.destroy_process_group()
+    except BaseException:
+        if run.world > 1:
+            import traceback
+            traceback.print_exc()
+            sys.stderr.flush()
+            os._exit(1)
+        raise
+    if run.world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -18,10 +18,7 @@ def main():
     dist.init_process_group('gloo')
     run = remcmc.Run(argv, cwd=cwd, rank=rank, world=world)
     run.make_engine = lambda: OracleEngine(O, run)
-    try:
-        run.main()
-    finally:
-        dist.destroy_process_group()
+    remcmc.run_guarded(run)
 
 
 if __name__ == '__main__':

@@ -83,3 +83,27 @@ def test_two_ranks_with_the_hip_engine_equal_one_rank(tmp_path, npn, world):
     if npn == 1:                                # the split-row sweep really moved configurations between the ranks
         th = np.loadtxt(str(two / 'mpg.lj.fcc.lammps.thrm'))
         assert len(th) == npn * tn * 4
+
+
+def test_a_failing_rank_ends_the_whole_job(tmp_path, oracle):
+    """An error on ONE rank (injected on rank 1 before it reaches its first barrier) must not leave rank 0 waiting in that
+    barrier for ever: the failing rank leaves with a failure code and the launcher ends the job (CPU, gloo, oracle stand-in)."""
+    argv = '-bm -n mpf -e LJ -ss 4 -pn 2 -tn 2 -sn 2 -sm 4'.split()
+    with pytest.raises(subprocess.CalledProcessError):
+        launch(2, tmp_path, argv, extra_env={'NM_TEST_FAIL_RANK': '1'})
+    launch(2, tmp_path, argv)            # the same job without the injection runs through
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_uses_rccl(tmp_path):
+    """bench.py launched the way the driver launches it (torch.distributed.run, one rank per GPU, backend nccl = RCCL): on this
+    one-GPU box that is a world of one, which still exercises the RCCL process group, its barrier and the max/sum all-reduce"""
+    import json
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(os.path.dirname(HERE), 'bench.py'), '--gpus', '1', '--steps', '2',
+           '--warmup', '1', '--no-cpu', '--scaling', 'strong']
+    r = subprocess.run(cmd, timeout=600, cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d['n_gpus'] == 1 and d['config']['backend'] == 'nccl' and d['config']['world_size_seen_by_backend'] == 1
+    assert d['scaling'] == 'strong' and d['config']['replicas_total'] == 64 and d['value'] > 1e5
