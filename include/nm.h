@@ -146,6 +146,9 @@ int nm_set_exchange_tape(nm_ctx *ctx, const double *tape, int n);
 /* per-move records of the next nm_run_block calls: trace[nslots][mod][NM_TRACE_COLS] */
 int nm_set_trace(nm_ctx *ctx, int enable);
 int nm_get_trace(nm_ctx *ctx, double *trace, int mod);
+/* acceptance counters count[nslots][6] (ntp nap ntv nav nth nah) and ratios ratio[nslots][3] (float32 ap av ah) as gen_sample would
+   have left them (remcmc:685-691): lets a test hand nm_adapt the reference's own inputs.  Either pointer may be NULL. */
+int nm_set_counters(nm_ctx *ctx, const double *count, const float *ratio);
 /* slot -> buffer map after exchanges (which initial configuration sits in slot k) */
 int nm_get_perm(nm_ctx *ctx, int *perm);
 /* dh of every pair visited by the last nm_exchange, sweep order */

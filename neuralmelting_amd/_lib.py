@@ -18,7 +18,7 @@ NM_THERMO_COLS, NM_TRACE_COLS, NM_STATS_COLS = 17, 4, 4
 SYMBOLS = ('nm_create', 'nm_destroy', 'nm_last_error', 'nm_nslots', 'nm_natoms', 'nm_cus_per_replica', 'nm_get_const',
            'nm_set_state', 'nm_get_state', 'nm_init_lattice', 'nm_lattice_state', 'nm_set_thermo', 'nm_set_step', 'nm_run_md', 'nm_run_block', 'nm_get_thermo', 'nm_adapt',
            'nm_exchange', 'nm_synchronize', 'nm_get_status', 'nm_format_thrm', 'nm_format_traj', 'nm_append_outputs', 'nm_timing_reset', 'nm_timing_get', 'nm_stats_get', 'nm_eval',
-           'nm_set_rng_tape', 'nm_set_exchange_tape', 'nm_set_trace', 'nm_get_trace', 'nm_get_perm',
+           'nm_set_rng_tape', 'nm_set_exchange_tape', 'nm_set_trace', 'nm_get_trace', 'nm_get_perm', 'nm_set_counters',
            'nm_get_exchange_crit')
 
 
@@ -83,6 +83,7 @@ def load():
     L.nm_set_trace.argtypes = [vp, C.c_int]
     L.nm_get_trace.argtypes = [vp, c_double_p, C.c_int]
     L.nm_get_perm.argtypes = [vp, c_int_p]
+    L.nm_set_counters.argtypes = [vp, c_double_p, c_float_p]
     L.nm_get_exchange_crit.argtypes = [vp, c_double_p, C.c_int]
     for s in SYMBOLS:
         if s != 'nm_last_error':

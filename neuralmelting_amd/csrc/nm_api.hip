@@ -817,6 +817,16 @@ int nm_get_trace(nm_ctx *c, double *trace, int mod)
     return NM_OK;
 }
 
+int nm_set_counters(nm_ctx *c, const double *count, const float *ratio)
+{
+    if (!c) return NM_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (count) HIPCHK(c, hipMemcpy(c->d_count, count, sizeof(double) * 6 * c->nslots, hipMemcpyHostToDevice));
+    if (ratio) HIPCHK(c, hipMemcpy(c->d_ratio, ratio, sizeof(float) * 3 * c->nslots, hipMemcpyHostToDevice));
+    return NM_OK;
+}
+
 int nm_get_perm(nm_ctx *c, int *perm)
 {
     if (!c || !perm) return fail(c, NM_ERR_ARG, "nm_get_perm: null argument");

@@ -207,6 +207,12 @@ class Engine:
         self._chk(self.lib.nm_get_trace(self.h, _dp(tr), int(mod)))
         return tr
 
+    def set_counters(self, count=None, ratio=None):
+        """counters [nslots][6] and float32 ratios [nslots][3] as a block would have left them (input of adapt)"""
+        cn = None if count is None else np.ascontiguousarray(count, dtype=np.float64)
+        ra = None if ratio is None else np.ascontiguousarray(ratio, dtype=np.float32)
+        self._chk(self.lib.nm_set_counters(self.h, _dp(cn), None if ra is None else ra.ctypes.data_as(B.c_float_p)))
+
     def perm(self):
         p = np.empty(self.nslots, dtype=np.int32)
         self._chk(self.lib.nm_get_perm(self.h, p.ctypes.data_as(B.c_int_p)))

@@ -24,6 +24,38 @@ def test_G1_constants_engine(tag):
     e.close()
 
 
+def test_G1_constants_engine_al():
+    """init_constant in metal units (remcmc:124-127) as the reference computed it for the 8x8 Al grid"""
+    import neuralmelting_amd as nm
+    g = G['G1_constants']['al_8x8']
+    e = nm.Engine(256, np.float32(g['P']), np.float32(g['T']), element='Al')
+    et, pf = e.constants()
+    np.testing.assert_array_equal(et, g['et'])
+    np.testing.assert_array_equal(pf, g['pf'])
+    e.close()
+
+
+def test_G2_adapt_engine():
+    """nm_adapt_kernel on the reference's own gen_mc_param cases (remcmc:726-745): every golden case sits in one slot of a grid,
+    is handed its float32 ratios and step sizes, and must come back with the reference's step sizes, zeroed counters and ratios"""
+    import neuralmelting_amd as nm
+    cases = G['G2_adapt']
+    n = len(cases)
+    nt = n
+    P = np.linspace(1, 8, 1, dtype=np.float32)
+    T = np.linspace(0.25, 2.5, nt, dtype=np.float32)
+    e = nm.Engine(256, P, T)
+    steps = np.array([c['steps_in'] for c in cases])
+    e.set_state(dxdvdt=steps)
+    ratios = np.array([[0.0 if r != r else r for r in c['ratios']] for c in cases], dtype=np.float32)   # nan_to_num, remcmc:686-688
+    e.set_counters(count=np.full((n, 6), 7.0), ratio=ratios)
+    e.adapt()
+    rows = e.thermo()
+    np.testing.assert_array_equal(rows[:, 5:8], np.array([c['steps_out'] for c in cases]))
+    np.testing.assert_array_equal(rows[:, 8:], 0.0)                                                # counters and ratios zeroed
+    e.close()
+
+
 @pytest.mark.parametrize('idx', range(4))
 def test_G3_exchange_engine(idx):
     """the device sweep, fed the uniforms the reference drew, ends in the reference's arrangement"""
