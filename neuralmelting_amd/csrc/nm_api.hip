@@ -394,7 +394,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     CHK(dalloc(&c->d_prof, ns * 16)); CHK(hipMemset(c->d_prof, 0, ns * 16 * sizeof(unsigned long long)));
 #endif
     c->d_tape = nullptr; c->d_tape_off = nullptr; c->d_trace = nullptr; c->d_nbr = nullptr; c->d_aux = nullptr;
-    if (nbr_elems) CHK(hipMalloc(&c->d_nbr, ns * nbr_elems * sizeof(unsigned short)));
+    if (nbr_elems) CHK(hipMalloc(&c->d_nbr, ns * 2 * nbr_elems * sizeof(unsigned short))); // two lists per slot (Cfg::LIST2)
     if (c->aux_doubles) CHK(dalloc(&c->d_aux, ns * c->cus * c->aux_doubles));
     const size_t xbd = c->kind == 0 ? CfgSmall::XBUF_DOUBLES : c->kind == 1 ? CfgMid::XBUF_DOUBLES : CfgLarge::XBUF_DOUBLES;
     if (c->cus > 1) { CHK(dalloc(&c->d_xbuf, ns * 2 * xbd)); CHK(hipMemset(c->d_xbuf, 0, ns * 2 * xbd * sizeof(double))); }

@@ -119,7 +119,12 @@ struct Cfg {
     static constexpr size_t LDS_BYTES = OFF_RHO + (POT ? (size_t)NMAX * sizeof(double) : 0);
     // per-slot global spill when the saved copies do not fit in LDS: sav, savv, x0 (9 NMAX doubles) + images + wrap counts
     static constexpr size_t AUX_SAVES = SAVE_LDS ? (SAVEV_LDS ? 0 : (size_t)3 * NMAX) : (size_t)9 * NMAX + ((size_t)3 * NMAX * 3 + 7) / 8;
-    static constexpr size_t AUX_DOUBLES = AUX_SAVES + (SAVEF_LDS ? 0 : (size_t)3 * NMAX); // ... + the saved forces
+    // lists outside LDS are kept TWICE per slot (LIST2): a trial that rebuilt and is then rejected goes back to the list it started
+    // from instead of rebuilding again (Replica::save / rebuild / restore); with it the reference positions and the row lengths
+    // of that list (3 NMAX doubles + NMAX 16-bit counts per workgroup)
+    static constexpr bool LIST2 = !LIST_LDS_;
+    static constexpr size_t AUX_LIST2 = LIST2 ? (size_t)3 * NMAX + ((size_t)NMAX + 3) / 4 : 0;
+    static constexpr size_t AUX_DOUBLES = AUX_SAVES + (SAVEF_LDS ? 0 : (size_t)3 * NMAX) + AUX_LIST2; // ... + the saved forces + LIST2
     static constexpr size_t NBR_G_ELEMS = LIST_LDS ? 0 : (size_t)MAXNB * NMAX; // per-slot global list
     // Lists that live in HBM/L2 are stored in chunks of CH consecutive neighbours of one atom ([chunk][atom][CH]) so that one
     // 8-byte load brings four indices: the dependent L2 round trip per neighbour was the cost there.  LDS lists stay [slot][atom].
@@ -267,11 +272,16 @@ struct Replica {
     // slot k of this wave's copy of the rarely-touched uniform scalars (every lane of the wave reads / writes the same value)
     __device__ __forceinline__ double &ust(int k) const { return ((double *)(nm_lds + C::OFF_UST))[(tid >> 6) * C::UST_PER_WAVE + k]; }
     // block-uniform flags in ONE scalar register (three separate bools cost lane masks and spilled scalars in the hot loops)
-    enum : int { F_LIST_OK = 1, F_FRESH = 2, F_SAVED_FRESH = 4 };
+    enum : int { F_LIST_OK = 1, F_FRESH = 2, F_SAVED_FRESH = 4, F_LIST_SAVED = 8, F_REBUILT = 16 };
     int flags = 0;
     __device__ __forceinline__ bool fresh() const { return (flags & F_FRESH) != 0; }
     __device__ __forceinline__ void set_fresh(bool b) { flags = b ? (flags | F_FRESH) : (flags & ~F_FRESH); }
     int status = 0;
+    // LIST2: the other list of the slot, and what belongs to the list a move started from
+    GlobArr<double> x0s, y0s, z0s;
+    unsigned short *cnts = nullptr;
+    double L0s = 0.0;
+    int list_cur = 0;
     bool same_xcd = false; // all workgroups of the cluster run on one XCD (read from the hardware, not assumed from blockIdx)
     const double *tape = nullptr;
     int tpos = 0, tlen = 0;
@@ -302,7 +312,12 @@ struct Replica {
             double *a = p.aux_g + ((size_t)slot * p.cus + q_) * C::AUX_DOUBLES + C::AUX_SAVES;
             sfx.g = a; sfy.g = a + NMAX; sfz.g = a + 2 * (size_t)NMAX;
         }
-        if constexpr (!C::LIST_LDS) nbr.g = (IdxT *)p.nbr_g + (size_t)slot * C::NBR_G_ELEMS;
+        if constexpr (!C::LIST_LDS) {
+            nbr.g = (IdxT *)p.nbr_g + (size_t)slot * 2 * C::NBR_G_ELEMS; // two lists per slot, list_cur = 0
+            double *a = p.aux_g + ((size_t)slot * p.cus + q_) * C::AUX_DOUBLES + (C::AUX_DOUBLES - C::AUX_LIST2);
+            x0s.g = a; y0s.g = a + NMAX; z0s.g = a + 2 * (size_t)NMAX;
+            cnts = (unsigned short *)(a + 3 * (size_t)NMAX);
+        }
         if (p.tape) { tape = p.tape + p.tape_off[slot]; tlen = p.tape_off[slot + 1] - p.tape_off[slot]; }
     }
 
@@ -396,6 +411,9 @@ struct Replica {
             sx[i] = px[i]; sy[i] = py[i]; sz[i] = pz[i];
             if (with_v) { svx[i] = vx[i]; svy[i] = vy[i]; svz[i] = vz[i]; }
         }
+        // LIST2: the list in force now is the one to come back to if this move rebuilds and is then rejected
+        flags &= ~(F_LIST_SAVED | F_REBUILT);
+        if (C::LIST2 && (flags & F_LIST_OK)) flags |= F_LIST_SAVED;
         // the forces of the own atoms, if they belong to these positions
         flags = fresh() ? (flags | F_SAVED_FRESH) : (flags & ~F_SAVED_FRESH);
         if (fresh())
@@ -414,6 +432,20 @@ struct Replica {
         if (flags & F_SAVED_FRESH) {
             for (int i = a0 + tid; i < a1; i += BLOCK) { fx[i] = sfx[i]; fy[i] = sfy[i]; fz[i] = sfz[i]; }
             set_fresh(true);
+        }
+        if constexpr (C::LIST2) {
+            // the move rebuilt the list on the way and is rejected: the positions are back where the previous list was built
+            // for, and that list is still there (the rebuild went to the slot's other buffer).  Its validity is tested by the
+            // next evaluation like that of any list.
+            if ((flags & F_LIST_SAVED) && (flags & F_REBUILT)) {
+                list_cur ^= 1;
+                nbr.g = (IdxT *)p.nbr_g + ((size_t)(gslot - p.slot0) * 2 + list_cur) * C::NBR_G_ELEMS;
+                for (int i = tid; i < N; i += BLOCK) { x0[i] = x0s[i]; y0[i] = y0s[i]; z0[i] = z0s[i]; }
+                for (int i = a0 + tid; i < a1; i += BLOCK) cnt[i] = cnts[i];
+                L0 = L0s;
+                flags |= F_LIST_OK;
+            }
+            flags &= ~(F_LIST_SAVED | F_REBUILT);
         }
     }
     __device__ double sum_mv2()
@@ -478,6 +510,16 @@ struct Replica {
         float *xf = (float *)(nm_lds + C::OFF_FRC), *yf = xf + NMAX, *zf = yf + NMAX;
         for (int i = tid; i < N; i += BLOCK) { xf[i] = (float)px[i]; yf[i] = (float)py[i]; zf[i] = (float)pz[i]; }
         set_fresh(false); // the forces are gone
+        if constexpr (C::LIST2) {
+            if ((flags & F_LIST_SAVED) && !(flags & F_REBUILT)) { // first rebuild since save(): keep the list the move started from
+                for (int i = tid; i < N; i += BLOCK) { x0s[i] = x0[i]; y0s[i] = y0[i]; z0s[i] = z0[i]; }
+                for (int i = a0 + tid; i < a1; i += BLOCK) cnts[i] = cnt[i];
+                L0s = L0;
+                list_cur ^= 1;
+                nbr.g = (IdxT *)p.nbr_g + ((size_t)(gslot - p.slot0) * 2 + list_cur) * C::NBR_G_ELEMS;
+                flags |= F_REBUILT;
+            }
+        }
         const float Lf = (float)L, invLf = 1.0f / Lf;
         const double rl = p.rc + p.skin + 16.0 * L * 5.9604644775390625e-8;
         const float rl2 = (float)(rl * rl * (1.0 + 4.0e-6));
