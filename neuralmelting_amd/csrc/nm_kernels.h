@@ -477,17 +477,6 @@ struct Replica {
         else return ((size_t)(r / C::CH) * NMAX + i) * C::CH + (r % C::CH);
     }
 
-    // one 64-candidate step of a wave-per-atom row build: lanes that hold a candidate in range append it to row i in lane order
-    __device__ __forceinline__ void append_step(int i, bool in, int j, int &base)
-    {
-        const unsigned long long m = __ballot(in);
-        if (in) {
-            const int r = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (r < MAXNB) nbr[nbr_at(r, i)] = (IdxT)j;
-        }
-        base += __popcll(m);
-    }
-
     // Verlet-list rebuild.
     // * The candidate test runs in fp32 on a float copy of the positions: VALU issue bounds the build and fp32 issues at twice the
     //   fp64 rate.  The copy lives in the force array, which is dead here: every caller of rebuild() is about to run the pair loop
@@ -495,8 +484,7 @@ struct Replica {
     //   1.5 L, difference, image shift, square: < 16 L 2^-24 in r), so the list is a superset of the exact one: the extra entries lie
     //   beyond rc + skin and are masked by the pair loop's exact fp64 cutoff test, contributing an exact zero in the same place
     //   of the sum.  (The list itself is not observable in any result.)
-    // * Lists in LDS (N <= 256, and the 6^3 system at 8 workgroups per replica): one WAVE per row, 64 candidates per step, ballot
-    //   compaction keeps the row sorted by j.
+    // * Lists in LDS (N <= 256, and the 6^3 system at 8 workgroups per replica): TPA threads per row (see below).
     // * Lists in HBM/L2 (one thread per atom in the pair loop): one THREAD per row.  All lanes of a wave test the same candidate
     //   j at the same time, so its coordinates are three broadcast LDS reads, there is no cross-lane step at all, and the loop over
     //   j unrolls into independent tests; a thread packs four indices into the 8-byte chunk the pair loop reads and stores it
@@ -507,8 +495,13 @@ struct Replica {
     __device__ void rebuild()
     {
         const int lane = tid & 63, wv = tid >> 6;
-        float *xf = (float *)(nm_lds + C::OFF_FRC), *yf = xf + NMAX, *zf = yf + NMAX;
-        for (int i = tid; i < N; i += BLOCK) { xf[i] = (float)px[i]; yf[i] = (float)py[i]; zf[i] = (float)pz[i]; }
+        constexpr int FSTRIDE = C::LIST_LDS ? NMAX + NMAX / 32 + 1 : NMAX; // LDS lists: skewed copy, element j at j + j / 32
+        float *xf = (float *)(nm_lds + C::OFF_FRC), *yf = xf + FSTRIDE, *zf = yf + FSTRIDE;
+        static_assert((size_t)3 * FSTRIDE * sizeof(float) <= (size_t)3 * NMAX * sizeof(double), "");
+        for (int i = tid; i < N; i += BLOCK) {
+            const int is = C::LIST_LDS ? i + (i >> 5) : i;
+            xf[is] = (float)px[i]; yf[is] = (float)py[i]; zf[is] = (float)pz[i];
+        }
         set_fresh(false); // the forces are gone
         if constexpr (C::LIST2) {
             if ((flags & F_LIST_SAVED) && !(flags & F_REBUILT)) { // first rebuild since save(): keep the list the move started from
@@ -526,26 +519,53 @@ struct Replica {
         int ovf = 0;
         __syncthreads(); // the float copy is complete
         if constexpr (C::LIST_LDS) {
-            for (int i = a0 + wv; i < a1; i += NW) { // this workgroup's rows of the list
-                const float xi = xf[i], yi = yf[i], zi = zf[i];
-                int base = 0;
-                for (int j0 = 0; j0 < N; j0 += 256) { // four 64-candidate blocks in flight: the distance tests are independent
-                    bool in[4];
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int j = j0 + 64 * b + lane;
-                        in[b] = false;
-                        if (j < N && j != i) {
-                            float dx = xi - xf[j], dy = yi - yf[j], dz = zi - zf[j];
+            // TPA threads per row (the pair loop's grouping): thread (row, sub) tests the contiguous block of candidates
+            // j = sub * CH + k, k < CH = ceil(N / TPA) — 32 per round, branch-free, one bit each.  An exclusive scan of the hit
+            // counts over the TPA threads of the row gives every thread its place, and it appends its hits there: with one round
+            // (N <= 32 TPA: 256 atoms at 4 or 8 workgroups) the row comes out sorted by j, with more it is ordered by (round, j) — any
+            // order that is a function of the positions alone serves, it only fixes the summation order of the pair loop; what matters
+            // is that consecutive entries are mostly consecutive atoms, which keeps the pair loop's gathers off each other's banks
+            // (a (round, sub)-strided assignment, j = sub + TPA k, measured 5 % slower in the pair loop for that reason).  All 512
+            // threads work; the wave-per-row form this replaces kept one wave on a row through 256 candidates with a ballot + mbcnt +
+            // scattered byte stores per 64: ~5 us per rebuild of a 256-atom replica at 4 workgroups, as much as an HMC step, 2.4
+            // times per move once the chains have equilibrated.
+            // The float copy is read as cf[j + j / 32]: the TPA blocks start 32 apart, and without the skew the candidates a wave
+            // instruction touches (one per sub) would all sit in one LDS bank.
+            const int g = tid / TPA, sub = tid - g * TPA;
+            const int CH = (N + TPA - 1) / TPA;
+            for (int i0 = a0; i0 < a1; i0 += G) { // uniform trip count: the scans below need every lane
+                const bool active = i0 + g < a1;
+                const int i = active ? i0 + g : a1 - 1;
+                const float xi = xf[i + (i >> 5)], yi = yf[i + (i >> 5)], zi = zf[i + (i >> 5)];
+                int base = 0; // entries of the row placed by earlier rounds
+                for (int k0 = 0; k0 < CH; k0 += 32) {
+                    unsigned int m = 0u;
+#pragma unroll 1
+                    for (int b0 = 0; b0 < 32; b0 += 8) // eight tests in flight (unrolled further, the gathers of all 32 are hoisted
+#pragma unroll                                         //  and the kernel, already at its register limit, spills 239 VGPRs)
+                        for (int b = b0; b < b0 + 8; ++b) {
+                            const int k = k0 + b, j = sub * CH + k;
+                            const int jj = (k < CH && j < N) ? j : i;
+                            const int js = jj + (jj >> 5);
+                            float dx = xi - xf[js], dy = yi - yf[js], dz = zi - zf[js];
                             dx -= Lf * rintf(dx * invLf); dy -= Lf * rintf(dy * invLf); dz -= Lf * rintf(dz * invLf);
-                            in[b] = (dx * dx + dy * dy + dz * dz) < rl2;
+                            m |= ((dx * dx + dy * dy + dz * dz) < rl2 && jj != i) ? (1u << b) : 0u; // (jj == i also covers the padding)
                         }
-                    }
+                    int incl = __popc(m);
+                    const int mine_n = incl;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) append_step(i, in[b], j0 + 64 * b + lane, base);
+                    for (int d = 1; d < TPA; d <<= 1) { const int t = __shfl_up(incl, d, TPA); if (sub >= d) incl += t; }
+                    int r = base + incl - mine_n;
+                    base += __shfl(incl, TPA - 1, TPA);
+                    while (m) {
+                        const int j = sub * CH + k0 + (int)__builtin_ctz(m);
+                        m &= m - 1u;
+                        if (active && r < MAXNB) nbr[nbr_at(r, i)] = (IdxT)j;
+                        ++r;
+                    }
                 }
                 if (base > MAXNB) { ovf = 1; base = MAXNB; }
-                if (lane == 0) cnt[i] = (unsigned short)base;
+                if (active && sub == 0) cnt[i] = (unsigned short)base;
             }
         } else {
             static_assert(C::CH == 4 && sizeof(IdxT) == 2 && MAXNB % 4 == 0, "four 16-bit indices per 8-byte chunk");
@@ -566,13 +586,20 @@ struct Replica {
                     const int cxb = __float_as_int(xf[jl]), cyb = __float_as_int(yf[jl]), czb = __float_as_int(zf[jl]);
                     unsigned int m0 = 0u, m1 = 0u;
 #pragma unroll
-                    for (int b = 0; b < 64; ++b) {
-                        const float cx = __int_as_float(__builtin_amdgcn_readlane(cxb, b)), cy = __int_as_float(__builtin_amdgcn_readlane(cyb, b)),
-                                    cz = __int_as_float(__builtin_amdgcn_readlane(czb, b));
-                        float dx = xi - cx, dy = yi - cy, dz = zi - cz;
-                        dx -= Lf * rintf(dx * invLf); dy -= Lf * rintf(dy * invLf); dz -= Lf * rintf(dz * invLf);
-                        const unsigned int bit = ((dx * dx + dy * dy + dz * dz) < rl2 && j0 + b < N) ? (1u << (b & 31)) : 0u;
-                        if (b < 32) m0 |= bit; else m1 |= bit;
+                    for (int half = 0; half < 2; ++half) {
+                        unsigned int m = 0u;
+#pragma unroll 1
+                        for (int b0 = 0; b0 < 32; b0 += 8) // eight tests in flight; unrolled further the kernel spills more than it gains
+#pragma unroll
+                            for (int b = b0; b < b0 + 8; ++b) {
+                                const int ln = 32 * half + b;
+                                const float cx = __int_as_float(__builtin_amdgcn_readlane(cxb, ln)), cy = __int_as_float(__builtin_amdgcn_readlane(cyb, ln)),
+                                            cz = __int_as_float(__builtin_amdgcn_readlane(czb, ln));
+                                float dx = xi - cx, dy = yi - cy, dz = zi - cz;
+                                dx -= Lf * rintf(dx * invLf); dy -= Lf * rintf(dy * invLf); dz -= Lf * rintf(dz * invLf);
+                                m |= ((dx * dx + dy * dy + dz * dz) < rl2 && j0 + ln < N) ? (1u << b) : 0u;
+                            }
+                        if (half) m1 = m; else m0 = m;
                     }
                     if ((unsigned int)(i - j0) < 32u) m0 &= ~(1u << (i - j0)); // not the atom itself
                     else if ((unsigned int)(i - j0) < 64u) m1 &= ~(1u << (i - j0 - 32));
