@@ -282,11 +282,12 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     c->trace_on = 0; c->trace_mod = 0; c->trace_cap = 0; c->xtape_n = 0;
     c->ev_next = 0; c->launches = 0; c->total_ms = 0.0;
     // material tables, remcmc:873-893
-    // Verlet-list skin: not observable in results, only in the rebuild rate.  0.3 (LAMMPS's lj default) measured best at 256 atoms;
+    // Verlet-list skin: not observable in results, only in the rebuild rate.  (Round 1 took 0.3, LAMMPS's lj default, as best at 256 atoms —
+    // measured in the first cycles after the lattice start, when HMC steps are still short and rebuilds rare;
     // the O(N^2) rebuild of the larger cells favours fewer rebuilds (0.45: 6^3 -10 %, 8^3 -45 % per move)
     // (8^3, equilibrated chains, where a rebuild costs ~10 evaluations: 0.6 gives 107 ms per launch of C5's share against 121 at 0.45,
     // for +7 % while the chains still reject everything; 0.75 overflows the 160 list slots of the dense crystals)
-    c->skin = cfg->natoms <= 256 ? 0.3 : cfg->natoms <= 1024 ? 0.45 : 0.6;
+    c->skin = cfg->natoms <= 256 ? 0.4 : cfg->natoms <= 1024 ? 0.45 : 0.6; // (256 atoms, equilibrated: 7.1 / 6.8 / 6.8 ms per launch at 0.3 / 0.4 / 0.5)
     if (const char *e = std::getenv("NM_SKIN")) { const double v = std::atof(e); if (v > 0.0 && v < 1.0) c->skin = v; }
     c->lat = 1.122; c->mass = 1.0; c->kB = 1.0; c->mvv2e = 1.0; c->ftm2v = 1.0; c->nktv2p = 1.0;
     c->rc = 2.5; c->pot = 0;

@@ -123,11 +123,15 @@ def test_npt_virial_pressure_equals_imposed_pressure():
 
     def zscores(a):
         bm = a.reshape(nb, cycles // nb, 64).mean(1)
-        return (bm.mean(0) - Pi) / (bm.std(0, ddof=1) / np.sqrt(nb)), bm.mean(0) - Pi
+        se = bm.std(0, ddof=1) / np.sqrt(nb)
+        # a standard error from eight block means is itself noisy (a t statistic with 7 degrees of freedom exceeds 5 in one of 64
+        # slots every tenth run): no slot is trusted to be more precise than the typical one
+        se = np.maximum(se, np.median(se))
+        return (bm.mean(0) - Pi) / se, bm.mean(0) - Pi
     z, diff = zscores(pest)
-    assert (np.abs(z) < 5.0).all(), np.sort(np.abs(z))[-4:]    # measured: max 2.8 over the 64 slots
-    assert abs(z.mean()) < 0.5, z.mean()                        # measured: -0.05
-    assert abs(diff.mean()) < 0.02, diff.mean()                 # measured: -0.0016 (pressures 1 ... 8)
+    assert (np.abs(z) < 5.0).all(), np.sort(np.abs(z))[-4:]    # measured: max 2.8-3.1 over the 64 slots
+    assert abs(z.mean()) < 0.5, z.mean()                        # measured: -0.05 ... -0.09
+    assert abs(diff.mean()) < 0.02, diff.mean()                 # measured: -0.0016 ... -0.0065 (pressures 1 ... 8)
     z0, diff0 = zscores(pvir)                                   # without the impulsive term the same data are off by ~0.4:
     assert z0.mean() > 4.0 and diff0.mean() > 0.25              # a shifted potential, or W off by a factor, cannot pass
     # kinetic temperature: velocities are drawn at exactly T with 3N-3 degrees of freedom and lose the rotation

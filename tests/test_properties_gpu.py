@@ -157,7 +157,7 @@ def test_grid_that_cannot_be_resident_falls_back_to_fewer_workgroups_per_replica
 
 
 def test_a_block_that_ends_on_an_error_leaves_the_state_as_it_was(monkeypatch):
-    """whatever stops a block (here an injected list overflow at the sixth rebuild, i.e. in the middle of it): x, v, box of the
+    """whatever stops a block (here an injected list overflow at the fourth rebuild, i.e. in the middle of it): x, v, box of the
     slots that stopped are those of the block's start, so a caller can inspect or re-issue; slots that finished have moved on"""
     import ctypes as C
     import neuralmelting_amd as nm
@@ -169,7 +169,7 @@ def test_a_block_that_ends_on_an_error_leaves_the_state_as_it_was(monkeypatch):
     e.run_block(8)
     e.synchronize()
     x1, v1, box1, d1 = e.get_state()
-    monkeypatch.setenv('NM_INJECT_OVERFLOW', '5,1')
+    monkeypatch.setenv('NM_INJECT_OVERFLOW', '3,1')
     e.set_step(1)
     e.run_block(48)
     with pytest.raises(nm.NMError):
@@ -177,7 +177,7 @@ def test_a_block_that_ends_on_an_error_leaves_the_state_as_it_was(monkeypatch):
     monkeypatch.delenv('NM_INJECT_OVERFLOW')
     st = e.status()
     stopped = st != 0
-    assert stopped.sum() >= 32 and (st[stopped] == 1).all()                # NM_ST_LIST_OVERFLOW
+    assert 8 <= stopped.sum() < 64 and (st[stopped] == 1).all()            # NM_ST_LIST_OVERFLOW; the cold slots rebuild too rarely to be hit
     xo, vo, bo = np.empty((64, 768)), np.empty((64, 768)), np.empty(64)
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
     rc = e.lib.nm_get_state(e.h, 0, 64, dp(xo), dp(vo), dp(bo), None)     # the copy succeeds; the return code repeats the error
