@@ -257,12 +257,6 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
         return fail(nullptr, NM_ERR_UNSUPPORTED, "nm_create: elements LJ and Al have device force kernels in this build");
     if (cfg->element == NM_EL_AL && cfg->natoms > 256)
         return fail(nullptr, NM_ERR_UNSUPPORTED, "nm_create: element Al (EAM) is built for up to 256 atoms (4^3 cells)");
-    // iter_position_mc's single-atom energy difference is written for pair potentials; for the EAM it would also have to follow
-    // the density change of every neighbour of the moved atom.  Until that exists the combination is refused, not approximated.
-    if (cfg->element == NM_EL_AL && !cfg->bulk && cfg->ppos > 0.0)
-        return fail(nullptr, NM_ERR_UNSUPPORTED, "nm_create: element Al (EAM) has bulk position moves only (-bm); iterative single-atom "
-                                                 "moves are implemented for the pair potential (LJ)");
-
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, NM_ERR_HIP, "nm_create: no HIP device available (this engine has no CPU fallback)");

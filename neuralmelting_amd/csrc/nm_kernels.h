@@ -1277,6 +1277,61 @@ struct Replica {
         dE = s[0]; dW = s[1];
     }
 
+    // The same for the Sutton-Chen EAM: moving atom k changes its pair terms AND the density of every neighbour, old or new:
+    //   dE = eps [ sum_j ((a/r'_kj)^7 - (a/r_kj)^7) - c ( sum_j (sqrt(rho_j + drho_j) - sqrt(rho_j)) + sqrt(rho'_k) - sqrt(rho_k) ) ],
+    //   drho_j = (a/r'_kj)^6 - (a/r_kj)^6,  rho'_k = sum_j (a/r'_kj)^6.
+    // rho[] holds the densities of the current configuration (iter_densities at move start, kept up to date by the trial loop); thread
+    // j keeps its drho_j until the decision is known.  One work item per atom (N <= BLOCK), one block reduction.
+    __device__ void delta_single_sc(int k, double ox, double oy, double oz, double nx, double ny, double nz, double &dE, double &drho_mine,
+                                    double &rho_k_new)
+    {
+        static_assert(C::POT != 1 || NMAX <= BLOCK, "one thread per atom");
+        box_consts();
+        const double invL = bc_invL, rc2 = p.rc * p.rc, a2 = p.sc_a2;
+        double s[3] = { 0.0, 0.0, 0.0 };
+        drho_mine = 0.0;
+        const int j = tid;
+        if (j < N && j != k) {
+            const double xj = px[j], yj = py[j], zj = pz[j];
+            double ax = nx - xj, ay = ny - yj, az = nz - zj, bx = ox - xj, by = oy - yj, bz = oz - zj;
+            ax -= L * rint(ax * invL); ay -= L * rint(ay * invL); az -= L * rint(az * invL);
+            bx -= L * rint(bx * invL); by -= L * rint(by * invL); bz -= L * rint(bz * invL);
+            const double ra = ax * ax + ay * ay + az * az, rb = bx * bx + by * by + bz * bz;
+            const bool ina = ra < rc2, inb = rb < rc2;
+            const double qa = a2 * recip(ina ? ra : 1.0), qb = a2 * recip(inb ? rb : 1.0); // (a/r)^2
+            const double ga = ina ? qa * qa * qa : 0.0, gb = inb ? qb * qb * qb : 0.0;     // (a/r)^6
+            s[0] = ga * sqrt(qa) - gb * sqrt(qb);                                          // (a/r)^7, new - old
+            drho_mine = ga - gb;
+            const double rj = rho[j];
+            s[1] = sqrt(rj + drho_mine) - sqrt(rj);
+            s[2] = ga;
+        }
+        block_sum<3, NW, NVMAX>(s, red, parity);
+        rho_k_new = s[2];
+        dE = p.sc_eps * (s[0] - p.sc_c * (s[1] + sqrt(s[2]) - sqrt(rho[k])));
+    }
+    // densities of all atoms of the current configuration, O(N^2), one thread per atom (start of an iterative EAM position move)
+    __device__ void iter_densities()
+    {
+        box_consts();
+        const double invL = bc_invL, rc2 = p.rc * p.rc, a2 = p.sc_a2;
+        __syncthreads(); // rho[] may still be read by the evaluation that ended last
+        if (tid < N) {
+            const double xj = px[tid], yj = py[tid], zj = pz[tid];
+            double r = 0.0;
+            for (int i = 0; i < N; ++i) {
+                double dx = xj - px[i], dy = yj - py[i], dz = zj - pz[i];
+                dx -= L * rint(dx * invL); dy -= L * rint(dy * invL); dz -= L * rint(dz * invL);
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                const bool in = r2 < rc2 && i != tid;
+                const double q = a2 * recip(in ? r2 : 1.0);
+                r += in ? q * q * q : 0.0;
+            }
+            rho[tid] = r;
+        }
+        __syncthreads();
+    }
+
     // iter_position_mc (remcmc:505-549) with single-particle energy differences instead of N full evaluations.
     // Reference mode (iter_revert = 0) follows the reference literally: the coordinates gathered at move start stay on the
     // "Python side" un-remapped, every trial re-sends them and runs `run 0` (twice when the trial is rejected, remcmc:541-542),
@@ -1311,6 +1366,7 @@ struct Replica {
                 svx[k] = draw_scalar(S_ITER_ACC, m, (uint32_t)k);
             }
         __syncthreads();
+        if constexpr (C::POT == 1) iter_densities();
         for (int k = 0; k < N; ++k) {
             nt += 1.0;
             const double pe = U / et;
@@ -1322,8 +1378,10 @@ struct Replica {
                 nx = ox + 2.0 * (u0 - 0.5) * dx * p.lat; ny = oy + 2.0 * (u1 - 0.5) * dx * p.lat; nz = oz + 2.0 * (u2 - 0.5) * dx * p.lat;
                 nx -= floor(nx / boxl) * boxl; ny -= floor(ny / boxl) * boxl; nz -= floor(nz / boxl) * boxl; // remcmc:524
             }
-            double dE, dW;
-            delta_single(k, ox, oy, oz, nx, ny, nz, dE, dW);
+            double dE, dW = 0.0;
+            [[maybe_unused]] double drho = 0.0, rho_k_new = 0.0;
+            if constexpr (C::POT == 1) delta_single_sc(k, ox, oy, oz, nx, ny, nz, dE, drho, rho_k_new);
+            else delta_single(k, ox, oy, oz, nx, ny, nz, dE, dW);
             const double Unew = U + dE;
             const double de = Unew / et - pe;
             bool acc;
@@ -1343,9 +1401,14 @@ struct Replica {
                         im[3 * k + 2] = (short)(im[3 * k + 2] + runs * wn[3 * k + 2]);
                     }
                 }
+                if constexpr (C::POT == 1) { // the densities follow the move
+                    if (tid < N && tid != k) rho[tid] += drho;
+                    if (tid == (k % BLOCK)) rho[k] = rho_k_new;
+                }
                 U = Unew; W += dW;
                 set_fresh(false);
             }
+            if constexpr (C::POT == 1) __syncthreads(); // the next trial reads rho[k+1] in every thread
             runs += acc ? 1 : 2;
         }
         __syncthreads();
@@ -1573,7 +1636,8 @@ __global__ void __launch_bounds__(C::BLOCK) nm_probe_kernel(const KParams p)
 // Phases of the per-replica state machine.  The block kernel is written so that eval() — by far the largest
 // piece of code and the only one whose cost matters — has exactly ONE call site; every move is split into the
 // part before its energy/force evaluation and the part after it.
-enum : int { PH_INIT = 0, PH_BULK = 1, PH_VMC = 2, PH_HMC_START = 3, PH_HMC_STEP = 4 }; // PH_HMC_STEP: the trajectory's last evaluation
+enum : int { PH_INIT = 0, PH_BULK = 1, PH_VMC = 2, PH_HMC_START = 3, PH_HMC_STEP = 4, PH_ITER_END = 5 }; // PH_HMC_STEP: the trajectory's last
+// evaluation; PH_ITER_END: the evaluation that closes an iterative position move of the EAM (its virial is not carried through the trials)
 
 // one workgroup = one replica for MOD moves
 template <class C>
@@ -1679,6 +1743,12 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
                     }
                 return;
             }
+        } else if (phase == PH_ITER_END) { // iter_position_mc of the EAM: U, W of the final configuration are in (the reference's last `run 0`)
+            if (p.trace && writer) {
+                double *tr = p.trace + ((size_t)slot * p.mod + m) * 4;
+                tr[0] = 3.0; tr[1] = c_vol; tr[2] = c_volnew; tr[3] = R.U;
+            }
+            ++m;
         } else if (phase == PH_BULK) { // bulk_position_mc, remcmc:485-500
             const double penew = R.U / et;
             crit = penew - c_pe;
@@ -1763,11 +1833,16 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
             } else if (roll <= p.ppos) { // iter_position_mc: local energy differences, no full evaluation
                 double c2 = 0.0;
                 const int na = R.iter_pmc((uint32_t)m, et, dx, ntp, nap, c2);
-                if (p.trace && writer) {
-                    double *tr = p.trace + ((size_t)slot * p.mod + m) * 4;
-                    tr[0] = 3.0; tr[1] = (double)na; tr[2] = c2; tr[3] = R.U;
+                if constexpr (C::POT == 1) { // close the move with a full evaluation (c_vol, c_volnew are free during a position move)
+                    c_vol = (double)na; c_volnew = c2;
+                    phase = PH_ITER_END; pending = true;
+                } else {
+                    if (p.trace && writer) {
+                        double *tr = p.trace + ((size_t)slot * p.mod + m) * 4;
+                        tr[0] = 3.0; tr[1] = (double)na; tr[2] = c2; tr[3] = R.U;
+                    }
+                    ++m;
                 }
-                ++m;
                 PROF_END(13);
             } else if (roll <= p.ppos + p.pvol) { // volume_mc, remcmc:552-573
                 ntv += 1.0;

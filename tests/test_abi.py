@@ -55,15 +55,3 @@ def test_no_gpu_means_loud_error():
     with pytest.raises(nm.NMError) as e:
         nm.Engine(256, np.float32([1, 8]), np.float32([0.25, 2.5]))
     assert e.value.code == -2 and 'no HIP device' in str(e.value)
-
-
-def test_al_with_iterative_position_moves_is_refused():
-    """the single-atom energy difference of iter_position_mc exists for the pair potential only: the EAM + non-bulk combination
-    must fail at nm_create (before any device is touched), never sample with the wrong energy"""
-    import numpy as np
-    import neuralmelting_amd as nm
-    P = np.linspace(1, 8, 2, dtype=np.float32)
-    T = np.linspace(300, 900, 2, dtype=np.float32)
-    with pytest.raises(nm.NMError) as err:
-        nm.Engine(256, P, T, element='Al', bulk=False)
-    assert err.value.code == -4 and 'bulk position moves only' in str(err.value)

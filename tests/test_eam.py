@@ -95,3 +95,33 @@ def test_eam_block_trace_parity(oracle, monkeypatch, cus):
         e.adapt()
     assert (rows[:, 0] > 100).all()          # kinetic temperatures in kelvin
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('revert', [False, True])
+@pytest.mark.parametrize('cus', [1, 4])
+def test_eam_iterative_position_moves_parity(oracle, monkeypatch, cus, revert):
+    """iter_position_mc (remcmc:505-549, the reference's default without -bm) for element Al: the device follows the density change of
+    every neighbour of the moved atom in its single-atom energy difference; the oracle re-evaluates the whole system for every
+    trial, as the reference does.  Reference mode (a rejected trial is not undone) and the corrected one."""
+    import neuralmelting_amd as nm
+    monkeypatch.setenv('NM_CUS_PER_REPLICA', str(cus))
+    mod = 6
+    P, T = grids(1, 2, pr=(1.0, 8.0), tr=(300.0, 900.0))
+    kw = dict(ppos=0.5, pvol=0.2, bulk=False, iter_revert=revert)
+    loop = OracleLoop(oracle, 4, P, T, el='Al', **kw)
+    e = nm.Engine(256, P, T, element='Al', **kw)
+    assert e.cus_per_replica == cus
+    e.set_state(loop.x, loop.v, loop.box, loop.d)
+    e.set_trace(True)
+    e.run_block(mod)
+    rows = e.thermo()
+    tr = e.trace(mod)
+    loop.run_block(mod, 0)
+    ro = loop.rows()
+    assert (tr[:, :, 0] == 3.0).any()                                  # iterative moves did take place
+    np.testing.assert_array_equal(rows[:, 8:14], ro[:, 8:14])          # every one of the 256 decisions per move
+    np.testing.assert_allclose(rows[:, :5], ro[:, :5], rtol=1e-6)
+    x, v, box, d = e.get_state()
+    np.testing.assert_allclose(x, loop.x, rtol=0, atol=1e-8)
+    e.close()
