@@ -1591,7 +1591,8 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
 // Residency census (clusters only).  The workgroups of a cluster spin on one another, so the whole grid must be resident at once;
 // HIP promises nothing of the kind, and a CU taken by another process, a CU mask or a second stream would leave part of the grid
 // queued behind workgroups that wait for it.  Every workgroup signs in on one counter and waits (bounded: 200 us) until all have;
-// whoever gives up sets an abort bit that also fails every later arrival, so the verdict is unanimous.  Returns false when the
+// whoever gives up sets an abort bit (by compare-and-swap on the short count it saw) that also fails every later arrival, so the
+// verdict is unanimous.  Returns false when the
 // grid did not gather; the caller has touched nothing by then.
 template <class C>
 __device__ __forceinline__ bool residency_census(const KParams &p)
@@ -1607,9 +1608,11 @@ __device__ __forceinline__ bool residency_census(const KParams &p)
             const unsigned int v = __hip_atomic_load(p.census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (v == want) { ok = 1; break; }
             if (v & ABORT) break;
-            if (wall_clock64() - t0 > 20000ull) { // 200 us of the 100 MHz clock
-                ok = (atomicOr(p.census, ABORT) == want) ? 1 : 0;
-                break;
+            if (wall_clock64() - t0 > 20000ull) { // 200 us of the 100 MHz clock: give up — but only on a count that is still short.
+                // compare-and-swap, not an unconditional OR: had the last workgroup signed in meanwhile, an abort bit set on top of the
+                // full count would fail the workgroups that have not looked yet while this one passes
+                if (atomicCAS(p.census, v, v | ABORT) == v) break;
+                continue; // the counter moved: look again (a full count passes, somebody else's abort fails)
             }
             __builtin_amdgcn_s_sleep(4);
         }
