@@ -494,7 +494,7 @@ struct Replica {
     //   column binning with a 5 x 5 stencil in front of it gained only 1.3x and is gone again.
     __device__ void rebuild()
     {
-        const int lane = tid & 63, wv = tid >> 6;
+        [[maybe_unused]] const int lane = tid & 63;
         constexpr int FSTRIDE = C::LIST_LDS ? NMAX + NMAX / 32 + 1 : NMAX; // LDS lists: skewed copy, element j at j + j / 32
         float *xf = (float *)(nm_lds + C::OFF_FRC), *yf = xf + FSTRIDE, *zf = yf + FSTRIDE;
         static_assert((size_t)3 * FSTRIDE * sizeof(float) <= (size_t)3 * NMAX * sizeof(double), "");
