@@ -147,9 +147,10 @@ struct Cfg {
 // velocity all create / zero linear / zero angular (see Replica::hmc_velocities' comment below for the algebra).  A function of its
 // own, NOT inlined: it runs once per HMC move, and inlined its registers (sixteen running moments, Philox, log / sin / cos) were
 // live-range neighbours of everything the trajectory loop keeps, which the allocator then spilled into that loop.  All state it
-// touches is in LDS at constant offsets; scalars come and go by value.  Returns the new parity of the reduction buffer.
+// touches is in LDS at constant offsets; scalars come and go by value.  Makes ONE block reduction (the caller flips its buffer
+// parity) and returns sum m |v|^2 of the velocities it leaves.
 template <class C>
-__device__ __attribute__((noinline)) int velocity_create(double t, uint32_t tag, double L, int N, int gslot, int parity, double mass,
+__device__ __attribute__((noinline)) double velocity_create(double t, uint32_t tag, double L, int N, int gslot, int parity, double mass,
                                                          double mvv2e, double kB, uint32_t seed, uint32_t step, short *im_g)
 {
     constexpr int BLOCK = C::BLOCK, NW = C::NW;
@@ -226,7 +227,9 @@ __device__ __attribute__((noinline)) int velocity_create(double t, uint32_t tag,
         vy[i] = (vy[i] - c1) * sc - (w2 * dx - w0 * dz);
         vz[i] = (vz[i] - c2) * sc - (w0 * dy - w1 * dx);
     }
-    return parity;
+    // sum m |v'|^2 of what was just written, from the same moments: with u = sc (v - c), r = X - Xc and I omega = L,
+    // sum m |u - omega x r|^2 = sc^2 sum m |v - c|^2 - 2 omega.L + omega.I.omega = sc^2 s2 - omega.L   (the caller's H0 needs no pass of its own)
+    return sc * sc * s2 - (w0 * L0_ + w1 * L1_ + w2 * L2_);
 }
 
 template <class C>
@@ -268,7 +271,8 @@ struct Replica {
     // critical path between two pair loops of an HMC trajectory): 1/L, L/L0 and the squared list-validity bound
     double bc_L = -1.0, bc_L0 = -1.0, bc_invL = 0.0, bc_sc = 0.0, bc_thr2 = 0.0;
     bool bc_bad = true;
-    double psum[3] = { 0.0, 0.0, 0.0 }; // partial (then cluster-wide) sums of the last energy evaluation: 2U, 2W, 2 pairs
+    double psum[4] = { 0.0, 0.0, 0.0, 0.0 }; // partial (then cluster-wide) sums of the last energy evaluation: 2U, 2W, 2 pairs; sum m v.v of the
+                                             // own atoms when the evaluation made the last half kick of a trajectory
     // slot k of this wave's copy of the rarely-touched uniform scalars (every lane of the wave reads / writes the same value)
     __device__ __forceinline__ double &ust(int k) const { return ((double *)(nm_lds + C::OFF_UST))[(tid >> 6) * C::UST_PER_WAVE + k]; }
     // block-uniform flags in ONE scalar register (three separate bools cost lane masks and spilled scalars in the hot loops)
@@ -751,7 +755,7 @@ struct Replica {
     // position to the cluster and parks it in f[i] (the force has no other reader); positions themselves stay untouched until
     // the whole workgroup is through its pair loop.  The peers thus get the positions as early as they used to get forces.
     template <bool WANT_E>
-    __device__ __forceinline__ void pair_loop(double invL, double &eacc, double &wacc, double &nacc, bool fuse, double dtfm, double h)
+    __device__ __forceinline__ void pair_loop(double invL, double &eacc, double &wacc, double &nacc, double &kacc, bool fuse, double dtfm, double h)
     {
         double *xg = xb ? xb + (size_t)(gen & 1) * C::XBUF_DOUBLES : nullptr;
         const int g = tid / TPA, sub = tid - g * TPA;
@@ -886,6 +890,11 @@ struct Replica {
             if (WANT_E) { e = group_sum(e); w = group_sum(w); np = group_sum(np); }
             if (i < a1 && sub == 0) {
                 eacc += e; wacc += w; nacc += np;
+                if (WANT_E && fuse) { // the energy evaluation that ends a trajectory: final_integrate on the spot, kinetic energy along
+                    const double ux = __builtin_fma(dtfm, ax, vx[i]), uy = __builtin_fma(dtfm, ay, vy[i]), uz = __builtin_fma(dtfm, az, vz[i]);
+                    vx[i] = ux; vy[i] = uy; vz[i] = uz;
+                    kacc += p.mass * (ux * ux + uy * uy + uz * uz);
+                }
                 if (!WANT_E && fuse) {
                     double ux = __builtin_fma(dtfm, ax, vx[i]), uy = __builtin_fma(dtfm, ay, vy[i]), uz = __builtin_fma(dtfm, az, vz[i]);
                     ux = __builtin_fma(dtfm, ax, ux); uy = __builtin_fma(dtfm, ay, uy); uz = __builtin_fma(dtfm, az, uz);
@@ -909,7 +918,7 @@ struct Replica {
     // Two passes over the same full list: densities of the own atoms, (cluster: exchange them,) then forces with
     // fp = eps [ 7 (a/r)^7 - 6 (c/2)(1/sqrt(rho_i) + 1/sqrt(rho_j)) (a/r)^6 ] / r^2.
     template <bool WANT_E>
-    __device__ __forceinline__ void pair_loop_sc(double invL, double &eacc, double &wacc, double &nacc, bool fuse, double dtfm, double h);
+    __device__ __forceinline__ void pair_loop_sc(double invL, double &eacc, double &wacc, double &nacc, double &kacc, bool fuse, double dtfm, double h);
 
     // ------------------------------------------------------------------ cluster hand-off (Q workgroups per replica)
     // Data-tagged granules (MI355X guide, hand-off price list "handoff-1to1"): every exchanged double travels as ONE
@@ -1132,7 +1141,7 @@ struct Replica {
     // have_need: the caller already holds the rebuild decision for the current positions (advance_and_share) and the barrier
     // that goes with it.  An energy evaluation leaves this workgroup's partial sums in psum[]; finish_sums() makes U, W of them
     // (across the cluster, together with one more partial sum of the caller: the kinetic energy at the end of a trajectory).
-    __device__ void eval(bool have_need = false, bool pre_need = false)
+    __device__ void eval(bool have_need = false, bool pre_need = false, bool final_kick = false, double dtfm = 0.0)
     {
         if (status & (ST_SYNC_TIMEOUT | ST_LIST_OVERFLOW)) return; // learnt from the last hand-over: the cluster is leaving
         if (!(L >= 2.0 * p.rc)) { status |= ST_BOX_TOO_SMALL; __syncthreads(); return; } // minimum-image limit
@@ -1158,20 +1167,20 @@ struct Replica {
         box_consts();
         const double invL = bc_invL;
 
-        double eacc = 0.0, wacc = 0.0, nacc = 0.0;
+        double eacc = 0.0, wacc = 0.0, nacc = 0.0, kacc = 0.0;
         PROF_BEGIN();
         if (NM_DBG(16)) { }
-        else if constexpr (C::POT == 1) pair_loop_sc<true>(invL, eacc, wacc, nacc, false, 0.0, 0.0);
-        else pair_loop<true>(invL, eacc, wacc, nacc, false, 0.0, 0.0);
+        else if constexpr (C::POT == 1) pair_loop_sc<true>(invL, eacc, wacc, nacc, kacc, final_kick, dtfm, 0.0);
+        else pair_loop<true>(invL, eacc, wacc, nacc, kacc, final_kick, dtfm, 0.0);
         PROF_END(3);
         TLINE(3);
         PROF_BEGIN();
         st_evals += 1.0;
-        double s[3] = { eacc, wacc, nacc };
-        block_sum<3, NW, NVMAX>(s, red, parity); // over this workgroup's atoms
+        double s[4] = { eacc, wacc, nacc, kacc };
+        block_sum<4, NW, NVMAX>(s, red, parity); // over this workgroup's atoms
         PROF_END(4);
         TLINE(4);
-        psum[0] = s[0]; psum[1] = s[1]; psum[2] = s[2];
+        psum[0] = s[0]; psum[1] = s[1]; psum[2] = s[2]; psum[3] = s[3];
         ++tl_n;
         set_fresh(true);
     }
@@ -1191,11 +1200,11 @@ struct Replica {
         TLINE(2);
         box_consts();
         const double invL = bc_invL;
-        double eacc = 0.0, wacc = 0.0, nacc = 0.0;
+        double eacc = 0.0, wacc = 0.0, nacc = 0.0, kacc = 0.0;
         PROF_BEGIN();
         if (NM_DBG(16)) { }
-        else if constexpr (C::POT == 1) pair_loop_sc<false>(invL, eacc, wacc, nacc, true, dtfm, h);
-        else pair_loop<false>(invL, eacc, wacc, nacc, true, dtfm, h);
+        else if constexpr (C::POT == 1) pair_loop_sc<false>(invL, eacc, wacc, nacc, kacc, true, dtfm, h);
+        else pair_loop<false>(invL, eacc, wacc, nacc, kacc, true, dtfm, h);
         PROF_END(3);
         TLINE(3);
         PROF_BEGIN();
@@ -1237,11 +1246,16 @@ struct Replica {
     //   I about the COM            = raw second moments - M (|Xc|^2 1 - Xc Xc^T)   (parallel axis)
     // and one pass that writes v = sc (v - c) - omega x (X - Xc).  The second "zero linear" would subtract the round-off of
     // sum m v' / M (~1e-17 relative); it is left out.  Differences to the four-pass arithmetic are ~1e-15 relative.
-    __device__ __forceinline__ void hmc_velocities(double t, uint32_t tag)
+    __device__ __forceinline__ double hmc_velocities(double t, uint32_t tag)
     {
         short *img = nullptr;
         if constexpr (!C::SAVE_LDS) img = im.g;
-        parity = velocity_create<C>(t, tag, L, N, gslot, parity, p.mass, p.mvv2e, p.kB, p.seed, p.step, img);
+        const double mv2 = velocity_create<C>(t, tag, L, N, gslot, parity, p.mass, p.mvv2e, p.kB, p.seed, p.step, img);
+        parity ^= 1;
+        // thread tid wrote atoms tid, tid + BLOCK, ...; in a cluster the readers that follow (save, the first half kick) take
+        // the own atoms a0 + tid, ... — other threads' writes unless a0 == 0
+        if (Q > 1) __syncthreads();
+        return uniform(mv2);
     }
 
     // ------------------------------------------------------------------ the moves
@@ -1419,7 +1433,7 @@ struct Replica {
 
 template <class C>
 template <bool WANT_E>
-__device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &eacc, double &wacc, double &nacc, bool fuse, double dtfm, double h)
+__device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &eacc, double &wacc, double &nacc, double &kacc, bool fuse, double dtfm, double h)
 {
     const int g = tid / TPA, sub = tid - g * TPA;
     const double rc2 = p.rc * p.rc, a2 = p.sc_a2, eps = p.sc_eps, cc = p.sc_c;
@@ -1568,6 +1582,11 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
         if (WANT_E) { e = group_sum(e); w = group_sum(w); np = group_sum(np); }
         if (i < a1 && sub == 0) {
             eacc += e; wacc += w; nacc += np;
+            if (WANT_E && fuse) { // the energy evaluation that ends a trajectory: final_integrate on the spot, kinetic energy along
+                const double ux = __builtin_fma(dtfm, ax, vx[i]), uy = __builtin_fma(dtfm, ay, vy[i]), uz = __builtin_fma(dtfm, az, vz[i]);
+                vx[i] = ux; vy[i] = uy; vz[i] = uz;
+                kacc += p.mass * (ux * ux + uy * uy + uz * uz);
+            }
             if (!WANT_E && fuse) { // integrate and publish on the spot, as pair_loop does (the densities' exchange took generation gen-1)
                 double ux = __builtin_fma(dtfm, ax, vx[i]), uy = __builtin_fma(dtfm, ay, vy[i]), uz = __builtin_fma(dtfm, az, vz[i]);
                 ux = __builtin_fma(dtfm, ax, ux); uy = __builtin_fma(dtfm, ay, uy); uz = __builtin_fma(dtfm, az, uz);
@@ -1697,25 +1716,18 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
     double &mv2new = R.ust(18); // kinetic-energy sum delivered with the last evaluation of a trajectory
     mv2new = 0.0;
     bool have_need = false, pre_need = false; // rebuild decision delivered with a position hand-over (HMC steps)
-    double &c_h = R.ust(19), &c_dtfm = R.ust(20);
-    c_h = 0.0; c_dtfm = 0.0;
+    double &c_h = R.ust(19), &c_dtfm = R.ust(20), &mv2_0 = R.ust(21);
+    c_h = 0.0; c_dtfm = 0.0; mv2_0 = 0.0;
 
     for (;;) {
         const int st_before = R.status;
         if (!skip_eval) {
-            R.eval(have_need, pre_need);
-            // cluster-wide U, W of an energy evaluation — ONE exchange site.  The last evaluation of a trajectory (the only one
-            // in phase PH_HMC_STEP) takes the kinetic energy along in the same exchange.
-            if (!(st_before & fatal) && !(R.status & (ST_BOX_TOO_SMALL | ST_SYNC_TIMEOUT))) {
-                double extra = 0.0;
-                if (phase == PH_HMC_STEP) {
-                    for (int i = R.a0 + tid; i < R.a1; i += BLOCK) { // final_integrate of the last step
-                        R.vx[i] += c_dtfm * R.fx[i]; R.vy[i] += c_dtfm * R.fy[i]; R.vz[i] += c_dtfm * R.fz[i];
-                    }
-                    extra = R.own_mv2();
-                }
-                mv2new = R.finish_sums(extra);
-            }
+            // The last evaluation of a trajectory (the only one in phase PH_HMC_STEP) makes the final half kick in its pair-loop
+            // epilogue and sums the kinetic energy with U and W.
+            R.eval(have_need, pre_need, phase == PH_HMC_STEP, c_dtfm);
+            // cluster-wide U, W of an energy evaluation — ONE exchange site; the kinetic energy rides along.
+            if (!(st_before & fatal) && !(R.status & (ST_BOX_TOO_SMALL | ST_SYNC_TIMEOUT)))
+                mv2new = R.finish_sums(phase == PH_HMC_STEP ? R.psum[3] : 0.0);
         }
         skip_eval = false;
         have_need = false;
@@ -1769,7 +1781,7 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
         } else if (phase == PH_HMC_START) { // hamiltonian_mc after its "run 0", remcmc:609-616
             R.save(true);
             U0 = R.U; W0 = R.W;
-            c_pe = R.U / et + 0.5 * p.mvv2e * R.sum_mv2() / et; // etot
+            c_pe = R.U / et + 0.5 * p.mvv2e * mv2_0 / et; // etot; sum m v.v came with the velocities
             PROF_END(5 + prof_phase);
             // `run NSTPS` (fix nve): initial_integrate of step 1, then the NSTPS - 1 force-only evaluations, each of which
             // integrates in its pair loop (final_integrate of its step + initial_integrate of the next) and hands the new
@@ -1865,7 +1877,7 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
             } else { // hamiltonian_mc, remcmc:598-608
                 if (!p.md_mode) nth += 1.0;
                 const uint32_t tag = R.draw_tag((uint32_t)m);
-                R.hmc_velocities(q6(t), tag);
+                mv2_0 = R.hmc_velocities(q6(t), tag);
                 c_h = uniform(q6(dt)); // timestep %f
                 c_dtfm = 0.5 * c_h * p.ftm2v / p.mass;
                 R.wrap(); // run 0
