@@ -18,11 +18,8 @@ namespace nm {
 #ifndef NM_PAIR_W
 #define NM_PAIR_W 2 // listed neighbours a thread works on at once (pair_vec)
 #endif
-#ifndef NM_PIPELINED
-#define NM_PIPELINED 0 // 1: software-pipelined pair loop over LDS lists (gathers of the next pack in flight); measured equal within
-#endif                 // noise at two waves per SIMD (the other wave fills the stalls) at a higher register cost
-#ifndef NM_PIPE_W
-#define NM_PIPE_W 2 // neighbours per step of the software-pipelined pair loop over LDS lists (2 or 4)
+#ifndef NM_PRIO_SW
+#define NM_PRIO_SW 12 // pair loop over LDS lists: list entry at which the two waves of a SIMD swap priorities (see pair_loop)
 #endif
 constexpr int NVMAX = 16; // widest block reduction (the 16 raw moments of hmc_velocities)
 
@@ -724,32 +721,6 @@ struct Replica {
         pair_pre<WANT_E, W>(xj, yj, zj, ok, xi, yi, zi, invL, rc2, ax, ay, az, e, w, np);
     }
 
-    // PIPE_W consecutive neighbours of one thread, gathered from LDS ahead of the arithmetic (LDS lists).  Two per step with two
-    // waves on a SIMD; four when a wave has its SIMD to itself (256-thread workgroups: four dependency chains keep the fp64 pipe
-    // busy where two leave bubbles behind v_rcp_f64 and the compare -> mask hazards).
-    static constexpr int PIPE_W = NM_PIPE_W;
-    struct Pack { double x[PIPE_W], y[PIPE_W], z[PIPE_W]; };
-    // entries e .. e+PIPE_W-1 of list word wd = neighbours k .. of this thread; an entry at or beyond `mine` reads atom `self`
-    // instead (in bounds, multiplied away later)
-    __device__ __forceinline__ void gather_pack(Pack &b, unsigned long long wd, int e, int k, int mine, int self) const
-    {
-        constexpr int BITS = 8 * (int)sizeof(IdxT);
-#pragma unroll
-        for (int t = 0; t < PIPE_W; ++t) {
-            const int j = (k + t) < mine ? (int)((wd >> (BITS * (e + t))) & ((1ull << BITS) - 1ull)) : self;
-            b.x[t] = px[j]; b.y[t] = py[j]; b.z[t] = pz[j];
-        }
-    }
-    template <bool WANT_E>
-    __device__ __forceinline__ void compute_pack(const Pack &b, int k, int mine, double xi, double yi, double zi, double invL, double rc2,
-                                                 double &ax, double &ay, double &az, double &e, double &w, double &np)
-    {
-        bool ok[PIPE_W];
-#pragma unroll
-        for (int t = 0; t < PIPE_W; ++t) ok[t] = (k + t) < mine;
-        pair_pre<WANT_E, PIPE_W>(b.x, b.y, b.z, ok, xi, yi, zi, invL, rc2, ax, ay, az, e, w, np);
-    }
-
     // fuse (force-only evaluations inside an HMC trajectory): the lane that holds atom i's force integrates it on the spot —
     // both half kicks around this evaluation and the drift, same arithmetic as advance_and_share(two) — publishes the NEW
     // position to the cluster and parks it in f[i] (the force has no other reader); positions themselves stay untouched until
@@ -760,14 +731,19 @@ struct Replica {
         double *xg = xb ? xb + (size_t)(gen & 1) * C::XBUF_DOUBLES : nullptr;
         const int g = tid / TPA, sub = tid - g * TPA;
         const double rc2 = p.rc * p.rc;
+        // The two waves that share a SIMD (w and w + NW/2) do not share it evenly: the older one wins every arbitration it is
+        // ready for, finishes its rows ~1 us before the other, and the younger one then runs alone below the SIMD's fp64 issue
+        // rate.  So the younger wave holds the higher priority for its first NM_PRIO_SW list entries and the older one after
+        // that: both stay in the loop to the end (measured +2.9 % on the 4^3 cluster; either wave favoured throughout: no gain).
+        [[maybe_unused]] const bool young = (tid >> 6) >= NW / 2;
         for (int i0 = a0; i0 < a1; i0 += G) { // uniform trip count keeps the shuffles below convergent
             const int i = i0 + g;
             double ax = 0.0, ay = 0.0, az = 0.0, e = 0.0, w = 0.0, np = 0.0;
+            if constexpr (C::LIST_LDS) { if (young) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
             if (i < a1) {
                 const double xi = px[i], yi = py[i], zi = pz[i];
                 const int c = cnt[i];
-                [[maybe_unused]] double &e_ = e;
-                if constexpr (C::LIST_LDS && !NM_PIPELINED) {
+                if constexpr (C::LIST_LDS) {
                     constexpr int W = NM_PAIR_W, PW = C::PW, BITS = 8 * (int)sizeof(IdxT);
                     static_assert(PW % W == 0, "");
                     const unsigned long long *nb64 = (const unsigned long long *)nbr.ptr();
@@ -776,6 +752,7 @@ struct Replica {
                         const unsigned long long wd = nb64[((size_t)(k0 >> C::LOG2PW) * C::NLIST + lrow(i)) * TPA + sub];
 #pragma unroll
                         for (int e0 = 0; e0 < PW; e0 += W) {
+                            if (k0 + e0 == NM_PRIO_SW) { if (young) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
                             if (k0 + e0 < mine) {
                                 int jj[W];
                                 bool ok[W];
@@ -786,67 +763,6 @@ struct Replica {
                                 }
                                 pair_vec<WANT_E, W>(jj, ok, xi, yi, zi, invL, rc2, ax, ay, az, e, w, np);
                             }
-                        }
-                    }
-                } else if constexpr (C::LIST_LDS) {
-                    // Software pipeline over pairs of neighbours.  A thread works on ~10 neighbours per evaluation (80 listed
-                    // neighbours over TPA = 8 threads): issued just in time, every pair of them paid an LDS round trip (index
-                    // -> address -> three bank-conflicted gathers) in front of its ~35-instruction dependent fp64 chains, and the
-                    // loop ran at ~40 % of its VALU bound.  Here the six gathers of the NEXT pair and the list word after the
-                    // current one are in flight while a pair is computed.  Control flow is wave-uniform (ballots); a thread that
-                    // has run out of neighbours gathers its own atom and multiplies the result away.
-                    // The arithmetic is written out on both sides of "is there another pair" instead of skipping the gathers with
-                    // a branch: where two such paths meet the compiler must assume the fewer outstanding loads, and its s_waitcnt
-                    // in front of the pair loaded a step earlier then also waits for the gathers just issued.  For the same
-                    // reason the look-ahead list word is loaded unconditionally (index clamped), not under a branch.
-                    constexpr int PW = C::PW, NWORDS = MAXNB / (PW * TPA);
-                    static_assert(PW == 8 || PW == 4, "");
-                    const unsigned long long *nb64 = (const unsigned long long *)nbr.ptr();
-                    const int mine = (c - sub + TPA - 1) / TPA; // neighbours of atom i that this thread handles: slots sub, sub+TPA, ...
-                    const size_t wbase = (size_t)lrow(i) * TPA + sub, wstride = (size_t)C::NLIST * TPA;
-                    unsigned long long wd = nb64[wbase], wn = nb64[wbase + (NWORDS > 1 ? wstride : 0)];
-                    int wi = 1;
-                    constexpr int PK = PIPE_W, SPW = PW / PK; // steps per list word
-                    static_assert(PW % PK == 0, "");
-                    Pack A, B;
-                    gather_pack(A, wd, 0, 0, mine, i);
-                    // computes `cur` (neighbours k ...) while the gathers of `nxt` (entries e ... of word wd: neighbours k + PK ...)
-                    // fly; false when the wave has nothing beyond `cur`
-                    auto step = [&](const Pack &cur, Pack &nxt, int k, int e) -> bool {
-                        if (__ballot(k + PK < mine) == 0ull) {
-                            compute_pack<WANT_E>(cur, k, mine, xi, yi, zi, invL, rc2, ax, ay, az, e_, w, np);
-                            asm volatile("; last pack of the wave"); // (two different markers: the optimiser would otherwise fold
-                            return false;                             //  the two copies of the arithmetic back into one block)
-                        }
-                        gather_pack(nxt, wd, e, k + PK, mine, i);
-                        __builtin_amdgcn_sched_barrier(0); // the gathers stay in front of the arithmetic that hides them
-                        compute_pack<WANT_E>(cur, k, mine, xi, yi, zi, invL, rc2, ax, ay, az, e_, w, np);
-                        asm volatile("; next pack in flight");
-                        return true;
-                    };
-                    auto next_word = [&]() {
-                        wd = wn;
-                        wi = wi + 1 < NWORDS ? wi + 1 : NWORDS - 1;
-                        wn = nb64[wbase + (size_t)wi * wstride];
-                    };
-                    for (int k = 0;; k += 2 * PW) { // two list words per trip when a word is a single step, else one
-                        if constexpr (SPW == 4) {       // 8 entries, 2 per step
-                            if (!step(A, B, k, 2)) break;
-                            if (!step(B, A, k + 2, 4)) break;
-                            if (!step(A, B, k + 4, 6)) break;
-                            next_word();
-                            if (!step(B, A, k + 6, 0)) break;
-                            k -= PW;
-                        } else if constexpr (SPW == 2) { // 8 entries, 4 per step, or 4 entries, 2 per step
-                            if (!step(A, B, k, PK)) break;
-                            next_word();
-                            if (!step(B, A, k + PK, 0)) break;
-                            k -= PW;
-                        } else {                          // 4 entries, 4 per step: two words per trip keep A / B roles fixed
-                            next_word();
-                            if (!step(A, B, k, 0)) break;
-                            next_word();
-                            if (!step(B, A, k + PK, 0)) break;
                         }
                     }
                 } else {
@@ -886,6 +802,7 @@ struct Replica {
                     }
                 }
             }
+            if constexpr (C::LIST_LDS) __builtin_amdgcn_s_setprio(0);
             ax = group_sum(ax); ay = group_sum(ay); az = group_sum(az);
             if (WANT_E) { e = group_sum(e); w = group_sum(w); np = group_sum(np); }
             if (i < a1 && sub == 0) {
