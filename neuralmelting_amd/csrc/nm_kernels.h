@@ -721,6 +721,16 @@ struct Replica {
         pair_pre<WANT_E, W>(xj, yj, zj, ok, xi, yi, zi, invL, rc2, ax, ay, az, e, w, np);
     }
 
+    // The two waves that share a SIMD (w and w + NW/2) do not share it evenly: the older one wins every arbitration it is
+    // ready for, finishes its rows ~1 us before the other, and the younger one then runs alone below the SIMD's fp64 issue
+    // rate.  So in the loops over LDS lists the younger wave holds the higher priority for its first NM_PRIO_SW list entries and
+    // the older one after that: both stay in the loop to the end (measured +2.9 % on the 4^3 cluster; either wave favoured
+    // throughout: no gain).
+    __device__ __forceinline__ bool young() const { return (tid >> 6) >= NW / 2; }
+    __device__ __forceinline__ void prio_begin() const { if constexpr (C::LIST_LDS) { if (young()) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } }
+    __device__ __forceinline__ void prio_swap() const { if constexpr (C::LIST_LDS) { if (young()) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); } }
+    __device__ __forceinline__ void prio_end() const { if constexpr (C::LIST_LDS) __builtin_amdgcn_s_setprio(0); }
+
     // fuse (force-only evaluations inside an HMC trajectory): the lane that holds atom i's force integrates it on the spot —
     // both half kicks around this evaluation and the drift, same arithmetic as advance_and_share(two) — publishes the NEW
     // position to the cluster and parks it in f[i] (the force has no other reader); positions themselves stay untouched until
@@ -731,15 +741,10 @@ struct Replica {
         double *xg = xb ? xb + (size_t)(gen & 1) * C::XBUF_DOUBLES : nullptr;
         const int g = tid / TPA, sub = tid - g * TPA;
         const double rc2 = p.rc * p.rc;
-        // The two waves that share a SIMD (w and w + NW/2) do not share it evenly: the older one wins every arbitration it is
-        // ready for, finishes its rows ~1 us before the other, and the younger one then runs alone below the SIMD's fp64 issue
-        // rate.  So the younger wave holds the higher priority for its first NM_PRIO_SW list entries and the older one after
-        // that: both stay in the loop to the end (measured +2.9 % on the 4^3 cluster; either wave favoured throughout: no gain).
-        [[maybe_unused]] const bool young = (tid >> 6) >= NW / 2;
         for (int i0 = a0; i0 < a1; i0 += G) { // uniform trip count keeps the shuffles below convergent
             const int i = i0 + g;
             double ax = 0.0, ay = 0.0, az = 0.0, e = 0.0, w = 0.0, np = 0.0;
-            if constexpr (C::LIST_LDS) { if (young) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+            prio_begin();
             if (i < a1) {
                 const double xi = px[i], yi = py[i], zi = pz[i];
                 const int c = cnt[i];
@@ -752,7 +757,7 @@ struct Replica {
                         const unsigned long long wd = nb64[((size_t)(k0 >> C::LOG2PW) * C::NLIST + lrow(i)) * TPA + sub];
 #pragma unroll
                         for (int e0 = 0; e0 < PW; e0 += W) {
-                            if (k0 + e0 == NM_PRIO_SW) { if (young) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+                            if (k0 + e0 == NM_PRIO_SW) prio_swap();
                             if (k0 + e0 < mine) {
                                 int jj[W];
                                 bool ok[W];
@@ -802,7 +807,7 @@ struct Replica {
                     }
                 }
             }
-            if constexpr (C::LIST_LDS) __builtin_amdgcn_s_setprio(0);
+            prio_end();
             ax = group_sum(ax); ay = group_sum(ay); az = group_sum(az);
             if (WANT_E) { e = group_sum(e); w = group_sum(w); np = group_sum(np); }
             if (i < a1 && sub == 0) {
@@ -1364,6 +1369,7 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
     for (int i0 = a0; i0 < a1; i0 += G) {
         const int i = i0 + g;
         double r = 0.0;
+        prio_begin();
         if (i < a1) {
             const double xi = px[i], yi = py[i], zi = pz[i];
             const int c = cnt[i];
@@ -1372,6 +1378,7 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
                 const unsigned long long wd = nb64[((size_t)(k0 >> 3) * NMAX + i) * TPA + sub];
 #pragma unroll
                 for (int e0 = 0; e0 < 8; e0 += W) {
+                    if (k0 + e0 == NM_PRIO_SW) prio_swap();
                     if (k0 + e0 < mine) {
                         double dx[W], dy[W], dz[W], r2[W], y[W], t[W], msk[W];
 #pragma unroll
@@ -1405,6 +1412,7 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
                 }
             }
         }
+        prio_end();
         r = group_sum(r);
         if (i < a1 && sub == 0) {
             rho[i] = r;
@@ -1440,6 +1448,7 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
     for (int i0 = a0; i0 < a1; i0 += G) {
         const int i = i0 + g;
         double ax = 0.0, ay = 0.0, az = 0.0, e = 0.0, w = 0.0, np = 0.0;
+        prio_begin();
         if (i < a1) {
             const double xi = px[i], yi = py[i], zi = pz[i], isi = rho[i];
             const int c = cnt[i];
@@ -1448,6 +1457,7 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
                 const unsigned long long wd = nb64[((size_t)(k0 >> 3) * NMAX + i) * TPA + sub];
 #pragma unroll
                 for (int e0 = 0; e0 < 8; e0 += W) {
+                    if (k0 + e0 == NM_PRIO_SW) prio_swap();
                     if (k0 + e0 < mine) {
                         double dx[W], dy[W], dz[W], r2[W], y[W], t[W], hh[W], msk[W], rj[W], q2[W], rm[W], rn[W], fp[W];
 #pragma unroll
@@ -1495,6 +1505,7 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
                 }
             }
         }
+        prio_end();
         ax = group_sum(ax); ay = group_sum(ay); az = group_sum(az);
         if (WANT_E) { e = group_sum(e); w = group_sum(w); np = group_sum(np); }
         if (i < a1 && sub == 0) {
