@@ -484,7 +484,11 @@ struct Replica {
     //   that rewrites it.  The radius is enlarged by the worst-case fp32 error (positions rounded to 2^-24 relative of at most
     //   1.5 L, difference, image shift, square: < 16 L 2^-24 in r), so the list is a superset of the exact one: the extra entries lie
     //   beyond rc + skin and are masked by the pair loop's exact fp64 cutoff test, contributing an exact zero in the same place
-    //   of the sum.  (The list itself is not observable in any result.)
+    //   of the sum.  (The list itself is not observable in any result.)  The copy is in units of the box edge, s = x / L, so that
+    //   the minimum image of a separation is fract(s_i - s_j + 1/2) - 1/2: with s_i + 1/2 held per row that is a subtraction,
+    //   v_fract_f32 and another subtraction per component instead of subtraction, multiplication, v_rndne and an fma (errors:
+    //   2^-24 of |s| <= 1.5, of s_i + 1/2 <= 2.5 and of their difference <= 3, fract and the last step exact: 7 x 2^-24 per
+    //   component, 12.2 L 2^-24 in r, inside the 16 L 2^-24 allowed for).
     // * Lists in LDS (N <= 256, and the 6^3 system at 8 workgroups per replica): TPA threads per row (see below).
     // * Lists in HBM/L2 (one thread per atom in the pair loop): one THREAD per row.  All lanes of a wave test the same candidate
     //   j at the same time, so its coordinates are three broadcast LDS reads, there is no cross-lane step at all, and the loop over
@@ -499,9 +503,10 @@ struct Replica {
         constexpr int FSTRIDE = C::LIST_LDS ? NMAX + NMAX / 32 + 1 : NMAX; // LDS lists: skewed copy, element j at j + j / 32
         float *xf = (float *)(nm_lds + C::OFF_FRC), *yf = xf + FSTRIDE, *zf = yf + FSTRIDE;
         static_assert((size_t)3 * FSTRIDE * sizeof(float) <= (size_t)3 * NMAX * sizeof(double), "");
+        const double invLd = 1.0 / L;
         for (int i = tid; i < N; i += BLOCK) {
             const int is = C::LIST_LDS ? i + (i >> 5) : i;
-            xf[is] = (float)px[i]; yf[is] = (float)py[i]; zf[is] = (float)pz[i];
+            xf[is] = (float)(px[i] * invLd); yf[is] = (float)(py[i] * invLd); zf[is] = (float)(pz[i] * invLd);
         }
         set_fresh(false); // the forces are gone
         if constexpr (C::LIST2) {
@@ -514,9 +519,8 @@ struct Replica {
                 flags |= F_REBUILT;
             }
         }
-        const float Lf = (float)L, invLf = 1.0f / Lf;
         const double rl = p.rc + p.skin + 16.0 * L * 5.9604644775390625e-8;
-        const float rl2 = (float)(rl * rl * (1.0 + 4.0e-6));
+        const float rl2 = (float)(rl * rl * invLd * invLd * (1.0 + 4.0e-6)); // in units of L^2, like the copy
         int ovf = 0;
         __syncthreads(); // the float copy is complete
         if constexpr (C::LIST_LDS) {
@@ -537,21 +541,24 @@ struct Replica {
             for (int i0 = a0; i0 < a1; i0 += G) { // uniform trip count: the scans below need every lane
                 const bool active = i0 + g < a1;
                 const int i = active ? i0 + g : a1 - 1;
-                const float xi = xf[i + (i >> 5)], yi = yf[i + (i >> 5)], zi = zf[i + (i >> 5)];
+                const float xi = xf[i + (i >> 5)] + 0.5f, yi = yf[i + (i >> 5)] + 0.5f, zi = zf[i + (i >> 5)] + 0.5f;
                 int base = 0; // entries of the row placed by earlier rounds
                 for (int k0 = 0; k0 < CH; k0 += 32) {
                     unsigned int m = 0u;
+                    const int jb = sub * CH + k0;
 #pragma unroll 1
                     for (int b0 = 0; b0 < 32; b0 += 8) // eight tests in flight (unrolled further, the gathers of all 32 are hoisted
 #pragma unroll                                         //  and the kernel, already at its register limit, spills 239 VGPRs)
                         for (int b = b0; b < b0 + 8; ++b) {
-                            const int k = k0 + b, j = sub * CH + k;
-                            const int jj = (k < CH && j < N) ? j : i;
-                            const int js = jj + (jj >> 5);
-                            float dx = xi - xf[js], dy = yi - yf[js], dz = zi - zf[js];
-                            dx -= Lf * rintf(dx * invLf); dy -= Lf * rintf(dy * invLf); dz -= Lf * rintf(dz * invLf);
-                            m |= ((dx * dx + dy * dy + dz * dz) < rl2 && jj != i) ? (1u << b) : 0u; // (jj == i also covers the padding)
+                            const int j = jb + b, js = j + (j >> 5); // (beyond the block or N: whatever lies there, masked below)
+                            // minimum image in units of L: fract(s_i - s_j + 1/2) - 1/2 (three instructions per component)
+                            const float ux = __builtin_amdgcn_fractf(xi - xf[js]) - 0.5f, uy = __builtin_amdgcn_fractf(yi - yf[js]) - 0.5f,
+                                        uz = __builtin_amdgcn_fractf(zi - zf[js]) - 0.5f;
+                            m |= (ux * ux + uy * uy + uz * uz) < rl2 ? (1u << b) : 0u;
                         }
+                    const int valid = min(32, min(CH - k0, N - jb)); // candidates of this round that exist
+                    m &= valid >= 32 ? 0xFFFFFFFFu : valid > 0 ? (1u << valid) - 1u : 0u;
+                    if ((unsigned int)(i - jb) < 32u) m &= ~(1u << (i - jb)); // not the atom itself
                     int incl = __popc(m);
                     const int mine_n = incl;
 #pragma unroll
@@ -559,7 +566,7 @@ struct Replica {
                     int r = base + incl - mine_n;
                     base += __shfl(incl, TPA - 1, TPA);
                     while (m) {
-                        const int j = sub * CH + k0 + (int)__builtin_ctz(m);
+                        const int j = jb + (int)__builtin_ctz(m);
                         m &= m - 1u;
                         if (active && r < MAXNB) nbr[nbr_at(r, i)] = (IdxT)j;
                         ++r;
@@ -574,7 +581,7 @@ struct Replica {
             for (int i0 = a0; i0 < a1; i0 += BLOCK) { // one thread per row; uniform trip count: every lane of a wave must take part
                 const bool active = i0 + tid < a1;    // in the candidate loads below (v_readlane reads lanes whatever their exec bit)
                 const int i = active ? i0 + tid : a1 - 1;
-                const float xi = xf[i], yi = yf[i], zi = zf[i];
+                const float xi = xf[i] + 0.5f, yi = yf[i] + 0.5f, zi = zf[i] + 0.5f;
                 int c = 0;
                 unsigned int lo = 0u, hi = 0u; // the chunk being filled: four 16-bit indices
                 for (int j0 = 0; j0 < N; j0 += 64) {
@@ -596,9 +603,9 @@ struct Replica {
                                 const int ln = 32 * half + b;
                                 const float cx = __int_as_float(__builtin_amdgcn_readlane(cxb, ln)), cy = __int_as_float(__builtin_amdgcn_readlane(cyb, ln)),
                                             cz = __int_as_float(__builtin_amdgcn_readlane(czb, ln));
-                                float dx = xi - cx, dy = yi - cy, dz = zi - cz;
-                                dx -= Lf * rintf(dx * invLf); dy -= Lf * rintf(dy * invLf); dz -= Lf * rintf(dz * invLf);
-                                m |= ((dx * dx + dy * dy + dz * dz) < rl2 && j0 + ln < N) ? (1u << b) : 0u;
+                                const float ux = __builtin_amdgcn_fractf(xi - cx) - 0.5f, uy = __builtin_amdgcn_fractf(yi - cy) - 0.5f,
+                                            uz = __builtin_amdgcn_fractf(zi - cz) - 0.5f;
+                                m |= ((ux * ux + uy * uy + uz * uz) < rl2 && j0 + ln < N) ? (1u << b) : 0u;
                             }
                         if (half) m1 = m; else m0 = m;
                     }
