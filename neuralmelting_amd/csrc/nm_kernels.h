@@ -678,11 +678,16 @@ struct Replica {
                                              double zi, double invL, double rc2, double &ax, double &ay, double &az, double &e, double &w,
                                              double &np)
     {
+        // minimum image: with c_i = x_i / L + 1/2 (the caller's xi, yi, zi; once per row) the separation is
+        // (fract(c_i - x_j / L) - 1/2) L: fma, v_fract_f64, fma per component instead of subtraction, multiplication, v_rndne, fma
         double dx[W], dy[W], dz[W], r2[W], y[W], t[W], fp[W];
+        const double mhL = -0.5 * L;
 #pragma unroll
-        for (int q = 0; q < W; ++q) { dx[q] = xi - xj[q]; dy[q] = yi - yj[q]; dz[q] = zi - zj[q]; }
+        for (int q = 0; q < W; ++q) { dx[q] = __builtin_fma(-xj[q], invL, xi); dy[q] = __builtin_fma(-yj[q], invL, yi); dz[q] = __builtin_fma(-zj[q], invL, zi); }
 #pragma unroll
-        for (int q = 0; q < W; ++q) { dx[q] -= L * rint(dx[q] * invL); dy[q] -= L * rint(dy[q] * invL); dz[q] -= L * rint(dz[q] * invL); }
+        for (int q = 0; q < W; ++q) { dx[q] = __builtin_amdgcn_fract(dx[q]); dy[q] = __builtin_amdgcn_fract(dy[q]); dz[q] = __builtin_amdgcn_fract(dz[q]); }
+#pragma unroll
+        for (int q = 0; q < W; ++q) { dx[q] = __builtin_fma(dx[q], L, mhL); dy[q] = __builtin_fma(dy[q], L, mhL); dz[q] = __builtin_fma(dz[q], L, mhL); }
         double msk[W];
 #pragma unroll
         for (int q = 0; q < W; ++q) {
@@ -753,7 +758,7 @@ struct Replica {
             double ax = 0.0, ay = 0.0, az = 0.0, e = 0.0, w = 0.0, np = 0.0;
             prio_begin();
             if (i < a1) {
-                const double xi = px[i], yi = py[i], zi = pz[i];
+                const double xi = __builtin_fma(px[i], invL, 0.5), yi = __builtin_fma(py[i], invL, 0.5), zi = __builtin_fma(pz[i], invL, 0.5); // (pair_pre)
                 const int c = cnt[i];
                 if constexpr (C::LIST_LDS) {
                     constexpr int W = NM_PAIR_W, PW = C::PW, BITS = 8 * (int)sizeof(IdxT);
