@@ -1370,7 +1370,7 @@ template <bool WANT_E>
 __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &eacc, double &wacc, double &nacc, double &kacc, bool fuse, double dtfm, double h)
 {
     const int g = tid / TPA, sub = tid - g * TPA;
-    const double rc2 = p.rc * p.rc, a2 = p.sc_a2, eps = p.sc_eps, cc = p.sc_c;
+    const double rc2 = p.rc * p.rc, a2 = p.sc_a2, eps = p.sc_eps, cc = p.sc_c, mhL = -0.5 * L;
     double *xg = xb ? xb + (size_t)(gen & 1) * C::XBUF_DOUBLES : nullptr;
     const unsigned long long mg = magic();
     // pass 1: densities of this workgroup's atoms.  Both passes walk the byte list like pair_loop does: one conflict-free 8-byte
@@ -1383,7 +1383,7 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
         double r = 0.0;
         prio_begin();
         if (i < a1) {
-            const double xi = px[i], yi = py[i], zi = pz[i];
+            const double xi = __builtin_fma(px[i], invL, 0.5), yi = __builtin_fma(py[i], invL, 0.5), zi = __builtin_fma(pz[i], invL, 0.5); // (minimum image as in pair_pre)
             const int c = cnt[i];
             const int mine = (c - sub + TPA - 1) / TPA;
             for (int k0 = 0; k0 < mine; k0 += 8) {
@@ -1397,11 +1397,14 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
                         for (int u = 0; u < W; ++u) {
                             const bool ok = (k0 + e0 + u) < mine;
                             const int j = ok ? (int)((wd >> (8 * (e0 + u))) & 0xFFull) : i;
-                            dx[u] = xi - px[j]; dy[u] = yi - py[j]; dz[u] = zi - pz[j];
+                            dx[u] = __builtin_fma(-px[j], invL, xi); dy[u] = __builtin_fma(-py[j], invL, yi); dz[u] = __builtin_fma(-pz[j], invL, zi);
                             msk[u] = ok ? 1.0 : 0.0;
                         }
 #pragma unroll
-                        for (int u = 0; u < W; ++u) { dx[u] -= L * rint(dx[u] * invL); dy[u] -= L * rint(dy[u] * invL); dz[u] -= L * rint(dz[u] * invL); }
+                        for (int u = 0; u < W; ++u) {
+                            dx[u] = __builtin_fma(__builtin_amdgcn_fract(dx[u]), L, mhL); dy[u] = __builtin_fma(__builtin_amdgcn_fract(dy[u]), L, mhL);
+                            dz[u] = __builtin_fma(__builtin_amdgcn_fract(dz[u]), L, mhL);
+                        }
 #pragma unroll
                         for (int u = 0; u < W; ++u) {
                             r2[u] = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
@@ -1462,7 +1465,7 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
         double ax = 0.0, ay = 0.0, az = 0.0, e = 0.0, w = 0.0, np = 0.0;
         prio_begin();
         if (i < a1) {
-            const double xi = px[i], yi = py[i], zi = pz[i], isi = rho[i];
+            const double xi = __builtin_fma(px[i], invL, 0.5), yi = __builtin_fma(py[i], invL, 0.5), zi = __builtin_fma(pz[i], invL, 0.5), isi = rho[i];
             const int c = cnt[i];
             const int mine = (c - sub + TPA - 1) / TPA;
             for (int k0 = 0; k0 < mine; k0 += 8) {
@@ -1476,12 +1479,15 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
                         for (int u = 0; u < W; ++u) {
                             const bool ok = (k0 + e0 + u) < mine;
                             const int j = ok ? (int)((wd >> (8 * (e0 + u))) & 0xFFull) : i;
-                            dx[u] = xi - px[j]; dy[u] = yi - py[j]; dz[u] = zi - pz[j];
+                            dx[u] = __builtin_fma(-px[j], invL, xi); dy[u] = __builtin_fma(-py[j], invL, yi); dz[u] = __builtin_fma(-pz[j], invL, zi);
                             rj[u] = rho[j];
                             msk[u] = ok ? 1.0 : 0.0;
                         }
 #pragma unroll
-                        for (int u = 0; u < W; ++u) { dx[u] -= L * rint(dx[u] * invL); dy[u] -= L * rint(dy[u] * invL); dz[u] -= L * rint(dz[u] * invL); }
+                        for (int u = 0; u < W; ++u) {
+                            dx[u] = __builtin_fma(__builtin_amdgcn_fract(dx[u]), L, mhL); dy[u] = __builtin_fma(__builtin_amdgcn_fract(dy[u]), L, mhL);
+                            dz[u] = __builtin_fma(__builtin_amdgcn_fract(dz[u]), L, mhL);
+                        }
 #pragma unroll
                         for (int u = 0; u < W; ++u) {
                             r2[u] = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
