@@ -688,12 +688,15 @@ struct Replica {
         for (int q = 0; q < W; ++q) { dx[q] = __builtin_amdgcn_fract(dx[q]); dy[q] = __builtin_amdgcn_fract(dy[q]); dz[q] = __builtin_amdgcn_fract(dz[q]); }
 #pragma unroll
         for (int q = 0; q < W; ++q) { dx[q] = __builtin_fma(dx[q], L, mhL); dy[q] = __builtin_fma(dy[q], L, mhL); dz[q] = __builtin_fma(dz[q], L, mhL); }
-        double msk[W];
+        // A listed neighbour beyond the cutoff, or a padded entry, is switched off by zeroing 1 / r^2 AFTER the reciprocal: every
+        // term below is a polynomial in it.  (A padded entry may be the atom itself: r2 = 0, reciprocal inf, Newton step NaN,
+        // all replaced by the select.)  Three instructions per neighbour fewer than guarding r2 in front and multiplying a 0 / 1
+        // mask into the force.
+        bool in[W];
 #pragma unroll
         for (int q = 0; q < W; ++q) {
             r2[q] = dx[q] * dx[q] + dy[q] * dy[q] + dz[q] * dz[q];
-            msk[q] = (ok[q] && r2[q] < rc2) ? 1.0 : 0.0; // multiplied in below: a select would be turned back into a divergent
-            r2[q] = ok[q] ? r2[q] : 1.0;                  // branch that serialises the W chains; a masked lane (r2 = 0) stays finite
+            in[q] = ok[q] && r2[q] < rc2;
         }
 #pragma unroll
         for (int q = 0; q < W; ++q) y[q] = __builtin_amdgcn_rcp(r2[q]);
@@ -710,11 +713,13 @@ struct Replica {
             for (int q = 0; q < W; ++q) y[q] = __builtin_fma(y[q], t[q], y[q]);
         } // y = 1/r2
 #pragma unroll
+        for (int q = 0; q < W; ++q) y[q] = in[q] ? y[q] : 0.0;
+#pragma unroll
         for (int q = 0; q < W; ++q) t[q] = y[q] * y[q] * y[q];              // 1/r6
 #pragma unroll
         for (int q = 0; q < W; ++q) {
-            fp[q] = t[q] * (48.0 * t[q] - 24.0) * y[q] * msk[q];
-            if (WANT_E) { e += t[q] * (4.0 * t[q] - 4.0) * msk[q]; np += msk[q]; }
+            fp[q] = t[q] * (48.0 * t[q] - 24.0) * y[q];
+            if (WANT_E) { e += t[q] * (4.0 * t[q] - 4.0); np += in[q] ? 1.0 : 0.0; }
         }
 #pragma unroll
         for (int q = 0; q < W; ++q) {
