@@ -1397,13 +1397,13 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
                 for (int e0 = 0; e0 < 8; e0 += W) {
                     if (k0 + e0 == NM_PRIO_SW) prio_swap();
                     if (k0 + e0 < mine) {
-                        double dx[W], dy[W], dz[W], r2[W], y[W], t[W], msk[W];
+                        double dx[W], dy[W], dz[W], r2[W], y[W], t[W];
+                        bool in[W]; // (switched off by zeroing 1 / r^2 after the reciprocal, as in pair_pre)
 #pragma unroll
                         for (int u = 0; u < W; ++u) {
-                            const bool ok = (k0 + e0 + u) < mine;
-                            const int j = ok ? (int)((wd >> (8 * (e0 + u))) & 0xFFull) : i;
+                            in[u] = (k0 + e0 + u) < mine;
+                            const int j = in[u] ? (int)((wd >> (8 * (e0 + u))) & 0xFFull) : i;
                             dx[u] = __builtin_fma(-px[j], invL, xi); dy[u] = __builtin_fma(-py[j], invL, yi); dz[u] = __builtin_fma(-pz[j], invL, zi);
-                            msk[u] = ok ? 1.0 : 0.0;
                         }
 #pragma unroll
                         for (int u = 0; u < W; ++u) {
@@ -1413,8 +1413,7 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
 #pragma unroll
                         for (int u = 0; u < W; ++u) {
                             r2[u] = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
-                            msk[u] = (msk[u] != 0.0 && r2[u] < rc2) ? 1.0 : 0.0;
-                            r2[u] = msk[u] != 0.0 ? r2[u] : 1.0; // a masked lane (itself: r2 = 0) stays finite
+                            in[u] = in[u] && r2[u] < rc2;
                         }
 #pragma unroll
                         for (int u = 0; u < W; ++u) y[u] = __builtin_amdgcn_rcp(r2[u]);
@@ -1425,9 +1424,9 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
 #pragma unroll
                         for (int u = 0; u < W; ++u) t[u] = __builtin_fma(-r2[u], y[u], 1.0);
 #pragma unroll
-                        for (int u = 0; u < W; ++u) y[u] = __builtin_fma(y[u], t[u], y[u]) * a2; // (a/r)^2
+                        for (int u = 0; u < W; ++u) y[u] = in[u] ? __builtin_fma(y[u], t[u], y[u]) * a2 : 0.0; // (a/r)^2
 #pragma unroll
-                        for (int u = 0; u < W; ++u) r += y[u] * y[u] * y[u] * msk[u];
+                        for (int u = 0; u < W; ++u) r += y[u] * y[u] * y[u];
                     }
                 }
             }
@@ -1479,14 +1478,14 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
                 for (int e0 = 0; e0 < 8; e0 += W) {
                     if (k0 + e0 == NM_PRIO_SW) prio_swap();
                     if (k0 + e0 < mine) {
-                        double dx[W], dy[W], dz[W], r2[W], y[W], t[W], hh[W], msk[W], rj[W], q2[W], rm[W], rn[W], fp[W];
+                        double dx[W], dy[W], dz[W], r2[W], y[W], t[W], hh[W], rj[W], q2[W], rm[W], rn[W], fp[W];
+                        bool in[W];
 #pragma unroll
                         for (int u = 0; u < W; ++u) {
-                            const bool ok = (k0 + e0 + u) < mine;
-                            const int j = ok ? (int)((wd >> (8 * (e0 + u))) & 0xFFull) : i;
+                            in[u] = (k0 + e0 + u) < mine;
+                            const int j = in[u] ? (int)((wd >> (8 * (e0 + u))) & 0xFFull) : i;
                             dx[u] = __builtin_fma(-px[j], invL, xi); dy[u] = __builtin_fma(-py[j], invL, yi); dz[u] = __builtin_fma(-pz[j], invL, zi);
                             rj[u] = rho[j];
-                            msk[u] = ok ? 1.0 : 0.0;
                         }
 #pragma unroll
                         for (int u = 0; u < W; ++u) {
@@ -1496,8 +1495,7 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
 #pragma unroll
                         for (int u = 0; u < W; ++u) {
                             r2[u] = dx[u] * dx[u] + dy[u] * dy[u] + dz[u] * dz[u];
-                            msk[u] = (msk[u] != 0.0 && r2[u] < rc2) ? 1.0 : 0.0;
-                            r2[u] = msk[u] != 0.0 ? r2[u] : 1.0;
+                            in[u] = in[u] && r2[u] < rc2;
                         }
 #pragma unroll
                         for (int u = 0; u < W; ++u) y[u] = __builtin_amdgcn_rsq(r2[u]);
@@ -1509,6 +1507,8 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
                             y[v] = __builtin_fma(y[v], t[v], y[v]);
                         }
 #pragma unroll
+                        for (int u = 0; u < W; ++u) y[u] = in[u] ? y[u] : 0.0; // 1 / r, or nothing at all
+#pragma unroll
                         for (int u = 0; u < W; ++u) { t[u] = y[u] * y[u]; q2[u] = a2 * t[u]; } // t = 1/r^2, q2 = (a/r)^2
 #pragma unroll
                         for (int u = 0; u < W; ++u) { rm[u] = q2[u] * q2[u] * q2[u]; }         // (a/r)^6
@@ -1517,12 +1517,12 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
 #pragma unroll
                         for (int u = 0; u < W; ++u) {
                             const double dF = 0.5 * cc * (isi + rj[u]);
-                            fp[u] = eps * (7.0 * rn[u] - 6.0 * dF * rm[u]) * t[u] * msk[u];
+                            fp[u] = eps * (7.0 * rn[u] - 6.0 * dF * rm[u]) * t[u];
                         }
 #pragma unroll
                         for (int u = 0; u < W; ++u) {
                             ax += dx[u] * fp[u]; ay += dy[u] * fp[u]; az += dz[u] * fp[u];
-                            if (WANT_E) { e += eps * rn[u] * msk[u]; w += r2[u] * fp[u]; np += msk[u]; }
+                            if (WANT_E) { e += eps * rn[u]; w += r2[u] * fp[u]; np += in[u] ? 1.0 : 0.0; }
                         }
                     }
                 }
