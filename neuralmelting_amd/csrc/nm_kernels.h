@@ -812,8 +812,8 @@ struct Replica {
                                     bool ok[W];
 #pragma unroll
                                     for (int r = 0; r < W; ++r) {
-                                        ok[r] = (first + e0 + r) < c; // tail entries of the last chunk are garbage
-                                        jj[r] = ok[r] ? (int)((cur[q] >> (16 * (e0 + r))) & 0xFFFFull) : i;
+                                        ok[r] = (first + e0 + r) < c; // the tail entries of a row's last chunk are zero (rebuild): atom 0, ignored
+                                        jj[r] = (int)((cur[q] >> (16 * (e0 + r))) & 0xFFFFull);
                                     }
                                     pair_vec<WANT_E, W>(jj, ok, xi, yi, zi, invL, rc2, ax, ay, az, e, w, np);
                                 }
