@@ -35,8 +35,8 @@ typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 192, unsigned char, true, true> C
 typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 256, unsigned char, true, true, 1> CfgSmallSC;
 typedef Cfg<NM_SMALL_BLOCK, 2 * NM_SMALL_TPA, 256, 256, unsigned char, true, true, 1> CfgSmallSCQ2;
 typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 256, unsigned char, true, true, 1> CfgSmallSCQ4;
-typedef Cfg<512, 1, 864, 160, unsigned short, false, true> CfgMid;     // N <= 864: list in HBM/L2, saved copies in LDS
-typedef Cfg<512, 1, 864, 160, unsigned short, false, true> CfgMidQ2;   // cluster variants: own atoms 432 / 216 / 108
+typedef Cfg<512, 1, 864, 160, unsigned short, false, true> CfgMid;     // N <= 864: list in HBM/L2, saved copies in LDS (also at 2 workgroups per replica)
+// cluster variants: own atoms 216 / 108
 typedef Cfg<512, 2, 864, 160, unsigned short, false, true> CfgMidQ4;
 // 8 workgroups per replica: 108 own atoms, whose list rows (16-bit, 35 KB) fit in LDS once the saved velocities moved to the spill
 typedef Cfg<512, 4, 864, 160, unsigned short, true, true, 0, 108, false> CfgMidQ8;
