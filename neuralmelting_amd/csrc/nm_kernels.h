@@ -1285,6 +1285,98 @@ struct Replica {
         __syncthreads();
     }
 
+    // exclusive prefix sum of one value per thread over the workgroup (thread order), and the total; ONE barrier (the two halves
+    // of `red` alternate as in block_sum).  Every thread sees the identical total.
+    __device__ __forceinline__ double block_scan(double v, double &total)
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        double incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const double t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        double *r = red.ptr() + parity * (NW * NVMAX);
+        if (lane == 63) r[wv * NVMAX] = incl;
+        __syncthreads();
+        double before = 0.0, all = 0.0;
+        for (int w = 0; w < NW; ++w) { const double t = r[w * NVMAX]; if (w < wv) before += t; all += t; }
+        parity ^= 1;
+        total = all;
+        return before + incl - v;
+    }
+
+    // The reference's iterative position move, all N trials at once.  In reference mode a trial is NEVER undone (remcmc:522-525:
+    // `od` aliases `x`), so the positions do not depend on the decisions: trial k sees the new positions of the atoms before it
+    // and the gathered ones of the atoms after it, whatever was accepted.  All N energy differences are therefore independent —
+    // two threads per trial, each over every other atom — the running energy the k-th criterion compares with is a prefix sum of
+    // them, and the decisions, counters and image-flag increments follow in one pass: ~40 us per move at 256 atoms instead of
+    // 256 serial trials of ~1.9 us.  The candidate positions and acceptance draws are in f[] and svx[] (iter_pmc); svy / svz
+    // (dead during a position move) take dE, dW.  Summation orders differ from the serial loop (~1e-16 relative).
+    __device__ int iter_pmc_all(double et, double &nt, double &na, double &crit)
+    {
+        box_consts();
+        const double invL = bc_invL, rc2 = p.rc * p.rc;
+        const double *const pos = px.ptr(), *const cand = fx.ptr(); // x, y, z follow one another NMAX doubles apart in both
+        for (int w0 = 0; w0 < 2 * N; w0 += BLOCK) {
+            const int w = w0 + tid, k = (w < 2 * N ? w : 0) >> 1, part = w & 1;
+            const double ox = px[k], oy = py[k], oz = pz[k], nx = fx[k], ny = fy[k], nz = fz[k];
+            double dE = 0.0, dW = 0.0;
+            for (int j = part; j < N; j += 2) {
+                const double *const src = j < k ? cand : pos; // atoms before k have moved already
+                const double xj = src[j], yj = src[NMAX + j], zj = src[2 * NMAX + j];
+                double ax = nx - xj, ay = ny - yj, az = nz - zj, bx = ox - xj, by = oy - yj, bz = oz - zj;
+                ax -= L * rint(ax * invL); ay -= L * rint(ay * invL); az -= L * rint(az * invL);
+                bx -= L * rint(bx * invL); by -= L * rint(by * invL); bz -= L * rint(bz * invL);
+                const double ra = ax * ax + ay * ay + az * az, rb = bx * bx + by * by + bz * bz;
+                const bool ina = (j != k) && ra < rc2, inb = (j != k) && rb < rc2;
+                const double ia = recip(ina ? ra : 1.0), ib = recip(inb ? rb : 1.0);
+                const double a6 = ia * ia * ia, b6 = ib * ib * ib;
+                const double sa = ina ? 1.0 : 0.0, sb = inb ? -1.0 : 0.0;
+                dE += sa * (a6 * (4.0 * a6 - 4.0)); dE += sb * (b6 * (4.0 * b6 - 4.0));
+                dW += sa * (a6 * (48.0 * a6 - 24.0)); dW += sb * (b6 * (48.0 * b6 - 24.0));
+            }
+            dE += __shfl_xor(dE, 1, 64); dW += __shfl_xor(dW, 1, 64); // the two halves of a trial sit in neighbouring lanes
+            if (w < 2 * N && part == 0) { svy[k] = dE; svz[k] = dW; }
+        }
+        __syncthreads();
+        // decisions: U_k = U + sum_{i<k} dE_i is what trial k starts from
+        int nacc = 0;
+        double Urun = U, Wsum = 0.0;
+        int runs0 = 0; // `run 0`s before the trials of this chunk (one per accepted trial, two per rejected one)
+        for (int k0 = 0; k0 < N; k0 += BLOCK) {
+            const int k = k0 + tid;
+            const bool have = k < N;
+            const double dE = have ? svy[k] : 0.0, dW = have ? svz[k] : 0.0;
+            double totE, totW;
+            const double before = block_scan(dE, totE);
+            (void)block_scan(dW, totW);
+            const double Uk = Urun + before, Unew = Uk + dE;
+            const double de = Unew / et - Uk / et;
+            const double metcrit = exp(-de);
+            const double mm = (metcrit != metcrit) ? metcrit : (metcrit < 1.0 ? metcrit : 1.0);
+            const bool acc = have && !isinf(metcrit) && svx[have ? k : 0] <= mm;
+            double totA, totR;
+            (void)block_scan(acc ? 1.0 : 0.0, totA);
+            const double runs_before = block_scan(have ? (acc ? 1.0 : 2.0) : 0.0, totR);
+            if (have) {
+                const int runs = runs0 + (int)runs_before; // the stale coordinate was remapped by every run 0 so far
+                px[k] = fx[k]; py[k] = fy[k]; pz[k] = fz[k];
+                im[3 * k] = (short)(im[3 * k] + runs * wn[3 * k]);
+                im[3 * k + 1] = (short)(im[3 * k + 1] + runs * wn[3 * k + 1]);
+                im[3 * k + 2] = (short)(im[3 * k + 2] + runs * wn[3 * k + 2]);
+                if (k == N - 1) red[2 * NW * NVMAX - 1] = de; // the criterion of the move's last trial (trace)
+            }
+            nacc += (int)totA;
+            runs0 += (int)totR;
+            Urun += totE; Wsum += totW;
+        }
+        __syncthreads();
+        crit = red[2 * NW * NVMAX - 1];
+        nt += (double)N; na += (double)nacc;
+        U = uniform(Urun); W = uniform(W + Wsum);
+        set_fresh(false); // f[] was used as scratch, the atoms have moved
+        __syncthreads();  // (red's last slot is free again before the next reduction could reach it)
+        return nacc;
+    }
+
     // iter_position_mc (remcmc:505-549) with single-particle energy differences instead of N full evaluations.
     // Reference mode (iter_revert = 0) follows the reference literally: the coordinates gathered at move start stay on the
     // "Python side" un-remapped, every trial re-sends them and runs `run 0` (twice when the trial is rejected, remcmc:541-542),
@@ -1319,6 +1411,9 @@ struct Replica {
                 svx[k] = draw_scalar(S_ITER_ACC, m, (uint32_t)k);
             }
         __syncthreads();
+        if constexpr (C::POT == 0) {
+            if (pre && !p.iter_revert) return iter_pmc_all(et, nt, na, crit);
+        }
         if constexpr (C::POT == 1) iter_densities();
         for (int k = 0; k < N; ++k) {
             nt += 1.0;
