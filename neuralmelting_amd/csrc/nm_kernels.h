@@ -898,7 +898,11 @@ struct Replica {
         int spins = 0;
         for (;;) {
             u64x2 w[K];
-            static_assert(K == 1 || K == 3 || K == 4, "granule reads come in ones, threes and fours");
+            static_assert(K == 1 || K == 2 || K == 3 || K == 4, "granule reads come in ones to fours");
+            if constexpr (K == 2)
+                asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(w[0]), "=&v"(w[1]) : "v"(g[0]), "v"(g[1]) : "memory");
+            else
             if constexpr (K == 4)
                 asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
                              "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
@@ -1315,11 +1319,17 @@ struct Replica {
         box_consts();
         const double invL = bc_invL, rc2 = p.rc * p.rc;
         const double *const pos = px.ptr(), *const cand = fx.ptr(); // x, y, z follow one another NMAX doubles apart in both
-        for (int w0 = 0; w0 < 2 * N; w0 += BLOCK) {
-            const int w = w0 + tid, k = (w < 2 * N ? w : 0) >> 1, part = w & 1;
+        // A cluster shares the trials out like the rows of the pair loop — workgroup q takes the atoms of its own range, TPA threads
+        // per trial — and hands the energy differences round (one hop, the position granules' slots).
+        const int g = tid / TPA, sub = tid - g * TPA;
+        double *xg = xb ? xb + (size_t)(gen & 1) * C::XBUF_DOUBLES : nullptr;
+        const unsigned long long mg = magic(), mgp = my_magic();
+        for (int i0 = a0; i0 < a1; i0 += G) { // uniform trip count (group_sum)
+            const bool have = i0 + g < a1;
+            const int k = have ? i0 + g : a1 - 1;
             const double ox = px[k], oy = py[k], oz = pz[k], nx = fx[k], ny = fy[k], nz = fz[k];
             double dE = 0.0, dW = 0.0;
-            for (int j = part; j < N; j += 2) {
+            for (int j = sub; j < N; j += TPA) {
                 const double *const src = j < k ? cand : pos; // atoms before k have moved already
                 const double xj = src[j], yj = src[NMAX + j], zj = src[2 * NMAX + j];
                 double ax = nx - xj, ay = ny - yj, az = nz - zj, bx = ox - xj, by = oy - yj, bz = oz - zj;
@@ -1333,10 +1343,27 @@ struct Replica {
                 dE += sa * (a6 * (4.0 * a6 - 4.0)); dE += sb * (b6 * (4.0 * b6 - 4.0));
                 dW += sa * (a6 * (48.0 * a6 - 24.0)); dW += sb * (b6 * (48.0 * b6 - 24.0));
             }
-            dE += __shfl_xor(dE, 1, 64); dW += __shfl_xor(dW, 1, 64); // the two halves of a trial sit in neighbouring lanes
-            if (w < 2 * N && part == 0) { svy[k] = dE; svz[k] = dW; }
+            dE = group_sum(dE); dW = group_sum(dW);
+            if (have && sub == 0) {
+                svy[k] = dE; svz[k] = dW;
+                if (Q > 1) { put_granule(xg + 2 * (size_t)k, dE, mgp); put_granule(xg + 2 * (size_t)(NMAX + k), dW, mgp); }
+            }
         }
-        __syncthreads();
+        if (Q > 1) {
+            int timeout = 0, poisoned = 0;
+            const int nown = a1 - a0, nother = N - nown;
+            for (int o = tid; o < nother; o += BLOCK) {
+                const int i = o < a0 ? o : o + nown;
+                double *const g2[2] = { xg + 2 * (size_t)i, xg + 2 * (size_t)(NMAX + i) };
+                double v2[2];
+                if (get_granules<2>(g2, mg, v2, timeout, poisoned)) { svy[i] = v2[0]; svz[i] = v2[1]; }
+            }
+            ++gen;
+            const int fl = block_any2<NW, NVMAX>(timeout != 0, poisoned != 0, red, parity);
+            if (fl & 1) status |= ST_SYNC_TIMEOUT;
+            if (fl & 2) status |= ST_LIST_OVERFLOW;
+            if (fl) return 0; // the cluster is leaving the block (the caller looks at the status)
+        } else __syncthreads();
         // decisions: U_k = U + sum_{i<k} dE_i is what trial k starts from
         int nacc = 0;
         double Urun = U, Wsum = 0.0;
@@ -1894,6 +1921,7 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
             } else if (roll <= p.ppos) { // iter_position_mc: local energy differences, no full evaluation
                 double c2 = 0.0;
                 const int na = R.iter_pmc((uint32_t)m, et, dx, ntp, nap, c2);
+                if (__builtin_amdgcn_readfirstlane(R.status) & fatal) break; // (its exchange of energy differences failed)
                 if constexpr (C::POT == 1) { // close the move with a full evaluation (c_vol, c_volnew are free during a position move)
                     c_vol = (double)na; c_volnew = c2;
                     phase = PH_ITER_END; pending = true;
