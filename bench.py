@@ -53,6 +53,7 @@ def main():
     ap.add_argument('--tn', type=int, default=None, help='override: temperatures (-tn)')
     ap.add_argument('--mod', type=int, default=None, help='override: moves per block (-sm)')
     ap.add_argument('--el', type=str, default=None, help='override: element (-e), LJ or Al')
+    ap.add_argument('--iterative', action='store_true', help="the reference's default position move (no -bm): N single-atom trials; implies --no-cpu")
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--cpu-seconds', type=float, default=6.0, help='target wall time of each cpu_baseline leg')
     args = ap.parse_args()
@@ -107,7 +108,7 @@ def main():
     P = np.linspace(1.0, 8.0, npn, dtype=np.float32)
     T = np.linspace(0.25, 2.5, tn, dtype=np.float32) if el == 'LJ' else np.linspace(256.0, 2560.0, tn, dtype=np.float32)
     natoms = 4 * sz ** 3
-    kw = dict(element=el, device=local, ppos=0.125, pvol=0.125, nstps=8, bulk=True, seed=256)
+    kw = dict(element=el, device=local, ppos=0.125, pvol=0.125, nstps=8, bulk=not args.iterative, seed=256)
     if split:
         nloc = npn * tn // world
         k0 = rank * nloc
@@ -211,8 +212,9 @@ def main():
             'metric': metric, 'value': value, 'unit': 'sweeps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': '%s; %s %d^3 cells (%d atoms), %d replicas on rank 0 (%d in all), MOD=%d, bulk PMC 0.125 / VMC '
-                                   '0.125 / HMC 0.75 x 8 steps, outputs off' % (desc, el, sz, natoms, ns, ns_total, mod),
+            'config': {'workload': '%s; %s %d^3 cells (%d atoms), %d replicas on rank 0 (%d in all), MOD=%d, %s PMC 0.125 / VMC '
+                                   '0.125 / HMC 0.75 x 8 steps, outputs off' % (desc, el, sz, natoms, ns, ns_total, mod,
+                                                                               'iterative' if args.iterative else 'bulk'),
                        'preset': args.config if not custom else None, 'replicas_per_gpu': ns, 'replicas_total': ns_total,
                        'sweeps_per_step': ns_total * mod,
                        'parallelism': ('rows/gpu' if not split else 'slots/gpu, split-row exchange over %s' % backend),
@@ -241,7 +243,7 @@ def main():
                            'accept_hmc': [round(float(a), 3) for a in last[:, 16]],
                            'pe_per_atom': [round(float(a) / natoms, 4) for a in last[:, 1]],
                            'vol_per_atom': [round(float(a) / natoms, 4) for a in last[:, 4]]}
-        if not args.no_cpu:
+        if not args.no_cpu and not args.iterative:  # (the CPU legs time bulk moves)
             out['cpu_baseline'] = cpu_baseline(eng, natoms, el, mod, T, tn, k0, args.cpu_seconds)
     if dist is not None:
         dist.barrier()
