@@ -5,7 +5,7 @@
 //   Replica::wrap + eval        "run 0"             remcmc:469,484,496,527,573,588,608,633
 //   Replica::eval               pair_style lj/cut 2.5 (or the Al EAM) energy/force/virial over a Verlet list
 //   nm_block_kernel, PH_BULK    bulk_position_mc    remcmc:477-502  (displace_atoms all random ...)
-//   Replica::iter_pmc           iter_position_mc    remcmc:505-549
+//   Replica::iter_pmc           iter_position_mc    remcmc:505-549  (reference mode: iter_pmc_all, the N trials of a move at once)
 //   nm_block_kernel, PH_VMC     volume_mc           remcmc:552-595  (change_box ... + scaled scatter)
 //   nm_block_kernel, PH_HMC_*   hamiltonian_mc      remcmc:598-640  (Replica::hmc_velocities = velocity create/zero; fix nve run NSTPS)
 //   end of nm_block_kernel      lammps_extract      remcmc:377-391 + ratios remcmc:685-688
