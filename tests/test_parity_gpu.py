@@ -95,6 +95,36 @@ def test_block_trace_parity(oracle, bulk):
     e.close()
 
 
+@pytest.mark.parametrize('cus', [1, 2, 4, 8])
+def test_iterative_moves_at_once_parity(oracle, monkeypatch, cus):
+    """a-3 in reference mode: the device evaluates the N trials of a move at once (Replica::iter_pmc_all: the positions do not
+    depend on the decisions because the reference never undoes a trial), shared out over the cluster at 2 / 4 / 8 workgroups per
+    replica; the oracle runs them one after the other as the reference does.  Position-move-heavy blocks, two of them, so that
+    image flags, counters and step sizes of the first feed the second; final positions and velocities compared as well."""
+    monkeypatch.setenv('NM_CUS_PER_REPLICA', str(cus))
+    sz, mod = 4, 12
+    P, T = grids(2, 2)
+    kw = dict(bulk=False, ppos=0.5, pvol=0.2)
+    loop = OracleLoop(oracle, sz, P, T, **kw)
+    e = make_engine(loop, sz, P, T, **kw)
+    assert e.cus_per_replica == cus
+    for step in range(2):
+        e.set_step(step)
+        e.run_block(mod)
+        rows = e.thermo()
+        loop.run_block(mod, step)
+        ro = loop.rows()
+        np.testing.assert_allclose(rows[:, :8], ro[:, :8], rtol=RTOL)
+        np.testing.assert_array_equal(rows[:, 8:], ro[:, 8:])       # counters and float32 ratios
+        e.adapt()
+        loop.adapt()
+    x, v, box, d = e.get_state()
+    np.testing.assert_allclose(x, loop.x, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(v, loop.v, rtol=0, atol=1e-7)
+    np.testing.assert_array_equal(d, loop.d)
+    e.close()
+
+
 @pytest.mark.parametrize('nstps', [1, 2, 3])
 @pytest.mark.parametrize('cus', [1, 2, 8])
 def test_short_trajectories_parity(oracle, monkeypatch, nstps, cus):
