@@ -577,6 +577,7 @@ struct Replica {
             }
         } else {
             static_assert(C::CH == 4 && sizeof(IdxT) == 2 && MAXNB % 4 == 0, "four 16-bit indices per 8-byte chunk");
+            static_assert((size_t)NMAX * 8 <= 65536, "the entries hold 8 x the atom index");
             unsigned long long *g = (unsigned long long *)nbr.ptr();
             for (int i0 = a0; i0 < a1; i0 += BLOCK) { // one thread per row; uniform trip count: every lane of a wave must take part
                 const bool active = i0 + tid < a1;    // in the candidate loads below (v_readlane reads lanes whatever their exec bit)
@@ -618,7 +619,7 @@ struct Replica {
                             const unsigned int j = (unsigned int)(j0 + 32 * half + __builtin_ctz(m));
                             m &= m - 1u;
                             if (c < MAXNB) {
-                                const unsigned int v = j << (16 * (c & 1));
+                                const unsigned int v = (j << 3) << (16 * (c & 1)); // the entry is the byte offset 8 j (pair_vec<.., BYTES>)
                                 if (c & 2) hi |= v; else lo |= v;
                                 if ((c & 3) == 3) { if (active) g[(size_t)(c >> 2) * NMAX + i] = ((unsigned long long)hi << 32) | lo; lo = hi = 0u; }
                             }
@@ -728,13 +729,20 @@ struct Replica {
         }
     }
     // the same with the gathers from LDS in front (lists that live in HBM/L2: their index loads are what is prefetched there)
-    template <bool WANT_E, int W>
+    // (BYTES: j holds byte offsets into the coordinate arrays, 8 x the atom index — what the lists in HBM store, so that the
+    //  gather's address needs no shift)
+    template <bool WANT_E, int W, bool BYTES = false>
     __device__ __forceinline__ void pair_vec(const int (&j)[W], const bool (&ok)[W], double xi, double yi, double zi, double invL,
                                              double rc2, double &ax, double &ay, double &az, double &e, double &w, double &np)
     {
         double xj[W], yj[W], zj[W];
 #pragma unroll
-        for (int q = 0; q < W; ++q) { xj[q] = px[j[q]]; yj[q] = py[j[q]]; zj[q] = pz[j[q]]; }
+        for (int q = 0; q < W; ++q) {
+            if constexpr (BYTES) {
+                xj[q] = *(const double *)((const char *)px.ptr() + j[q]); yj[q] = *(const double *)((const char *)py.ptr() + j[q]);
+                zj[q] = *(const double *)((const char *)pz.ptr() + j[q]);
+            } else { xj[q] = px[j[q]]; yj[q] = py[j[q]]; zj[q] = pz[j[q]]; }
+        }
         pair_pre<WANT_E, W>(xj, yj, zj, ok, xi, yi, zi, invL, rc2, ax, ay, az, e, w, np);
     }
 
@@ -813,9 +821,9 @@ struct Replica {
 #pragma unroll
                                     for (int r = 0; r < W; ++r) {
                                         ok[r] = (first + e0 + r) < c; // the tail entries of a row's last chunk are zero (rebuild): atom 0, ignored
-                                        jj[r] = (int)((cur[q] >> (16 * (e0 + r))) & 0xFFFFull);
+                                        jj[r] = (int)((cur[q] >> (16 * (e0 + r))) & 0xFFFFull); // 8 x the atom index
                                     }
-                                    pair_vec<WANT_E, W>(jj, ok, xi, yi, zi, invL, rc2, ax, ay, az, e, w, np);
+                                    pair_vec<WANT_E, W, true>(jj, ok, xi, yi, zi, invL, rc2, ax, ay, az, e, w, np);
                                 }
                             }
                         }
