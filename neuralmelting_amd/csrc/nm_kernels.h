@@ -719,8 +719,10 @@ struct Replica {
         for (int q = 0; q < W; ++q) t[q] = y[q] * y[q] * y[q];              // 1/r6
 #pragma unroll
         for (int q = 0; q < W; ++q) {
-            fp[q] = t[q] * (48.0 * t[q] - 24.0) * y[q];
-            if (WANT_E) { e += t[q] * (4.0 * t[q] - 4.0); np += in[q] ? 1.0 : 0.0; }
+            // in units of 24 (force, virial) and 4 (energy): 2 t - 1 and t - 1 take inline constants, whereas 48 t - 24 as an fma
+            // into a register preloaded with -24 cost two v_mov per neighbour; pair_loop scales the row's sums once at the end
+            fp[q] = t[q] * __builtin_fma(2.0, t[q], -1.0) * y[q];
+            if (WANT_E) { e += t[q] * (t[q] - 1.0); np += in[q] ? 1.0 : 0.0; }
         }
 #pragma unroll
         for (int q = 0; q < W; ++q) {
@@ -833,6 +835,8 @@ struct Replica {
                 }
             }
             prio_end();
+            ax *= 24.0; ay *= 24.0; az *= 24.0; // (pair_pre's units)
+            if (WANT_E) { e *= 4.0; w *= 24.0; }
             ax = group_sum(ax); ay = group_sum(ay); az = group_sum(az);
             if (WANT_E) { e = group_sum(e); w = group_sum(w); np = group_sum(np); }
             if (i < a1 && sub == 0) {
