@@ -53,8 +53,12 @@ def main():
     ap.add_argument('--tn', type=int, default=None, help='override: temperatures (-tn)')
     ap.add_argument('--mod', type=int, default=None, help='override: moves per block (-sm)')
     ap.add_argument('--el', type=str, default=None, help='override: element (-e), LJ or Al')
-    ap.add_argument('--iterative', action='store_true', help="the reference's default position move (no -bm): N single-atom trials; implies --no-cpu")
+    ap.add_argument('--iterative', action='store_true', help="the reference's default position move (no -bm): N single-atom trials")
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    ap.add_argument('--equil', type=int, default=30, help='cycles since the lattice start after which the chains count as equilibrated: '
+                    'after the timed window (cycles warmup .. warmup+steps) the run continues untimed up to this cycle, and until the '
+                    'mean HMC acceptance is within 0.4-0.6, then times `steps` cycles again (the sustained rate = `value`); 0 = window only')
+    ap.add_argument('--force-split', action='store_true', help='strong scaling: use the split-row (collective) exchange even where whole rows would do')
     ap.add_argument('--cpu-seconds', type=float, default=6.0, help='target wall time of each cpu_baseline leg')
     args = ap.parse_args()
 
@@ -98,7 +102,7 @@ def main():
         row0, nrows = rank * rows, rows
     else:
         npn = np_cfg if not custom else rows
-        if npn % world == 0:
+        if npn % world == 0 and not args.force_split:
             nrows = npn // world
             row0 = rank * nrows
         elif (npn * tn) % world == 0:  # fewer rows than ranks: even slot ranges, a pressure row spans ranks
@@ -127,20 +131,11 @@ def main():
         from neuralmelting_amd import remcmc
         et_all = np.array([remcmc.init_constant(P, T, el, *divmod(k, tn))[0] for k in range(npn * tn)])
         pf_all = np.array([remcmc.init_constant(P, T, el, *divmod(k, tn))[1] for k in range(npn * tn)])
-        info = (world, backend == 'nccl')
+        info = (world if dist is not None else 1, backend == 'nccl')
 
     def exchange_split(step):
-        """a pressure row spans ranks: all-gather (E_tot, V), identical sweep everywhere, re-seat what moved (exchange.py)"""
-        r = eng.thermo()
-        ev = X.allgather(np.stack([r[:, 1] + r[:, 2], r[:, 4]], axis=1), info)
-        perm, swaps = X.sweep(npn, tn, 256, step, ev[:, 0], ev[:, 1], et_all, pf_all)
-        if swaps:
-            xs, vs, bs, ds = eng.get_state()
-            pack = np.concatenate([xs, vs, bs[:, None], ds, r[:, :5]], axis=1)
-            allp = X.allgather(pack, info)[perm[k0:k0 + ns]]
-            n3 = 3 * natoms
-            eng.set_state(allp[:, :n3], allp[:, n3:2 * n3], allp[:, 2 * n3], allp[:, 2 * n3 + 1:2 * n3 + 4])
-            eng.set_thermo(allp[:, 2 * n3 + 4:2 * n3 + 9])
+        """a pressure row spans ranks: all-gather (E_tot, V), identical sweep everywhere, the swapped replicas move (exchange.py)"""
+        X.exchange_split(eng, step, npn, tn, 256, k0, natoms, et_all, pf_all, info, rank=rank)
 
     def cycle(step):
         eng.set_step(step)
@@ -158,31 +153,63 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(nsteps, step):
+        """exactly nsteps cycles between two fences; (seconds = max over ranks, replicas of all ranks, kernel launches, kernel ms, stats)"""
+        fence()
+        eng.timing_reset()
+        eng.stats(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            cycle(step)
+            step += 1
+        fence()
+        dt = time.perf_counter() - t0
+        ns_total = ns
+        if dist is not None:
+            tt = torch.tensor([dt, float(ns)], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
+            dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)
+            dt, ns_total = float(tt[0].item()), int(round(float(tt[1].item())))
+        launches, kms = eng.timing()
+        return step, dt, ns_total, launches, kms, eng.stats()
+
+    def hmc_acceptance(step):
+        """mean HMC acceptance over this rank's replicas of one more (untimed) cycle; agreed over the ranks"""
+        eng.set_step(step)
+        eng.run_block(mod)
+        a = float(eng.thermo()[:, 16].mean())
+        eng.adapt()
+        if split:
+            exchange_split(step)
+        else:
+            eng.exchange(count=False)
+        if dist is not None:
+            tt = torch.tensor([a], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            a = float(tt.item()) / dist.get_world_size()
+        return a
+
     step = 0
     for _ in range(args.warmup):
         cycle(step)
         step += 1
-    fence()
-    eng.timing_reset()
-    eng.stats(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        cycle(step)
-        step += 1
-    fence()
-    dt = time.perf_counter() - t0
-    ns_total = ns
-    if dist is not None:
-        tt = torch.tensor([dt, float(ns)], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
-        dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)
-        dt, ns_total = float(tt[0].item()), int(round(float(tt[1].item())))
-        world_seen = dist.get_world_size()
+    # ---- the window right after the warm-up the caller asked for (what rounds 1 and 2 reported)
+    step, dt_w, ns_total, launches_w, kms_w, st_w = timed(args.steps, step)
+    # ---- untimed equilibration, then the same number of timed cycles: the sustained rate
+    equil = 0
+    if args.equil > 0:
+        acc = None
+        while step < args.equil or acc is None or not (0.4 <= acc <= 0.6):
+            if step >= args.equil + 40:
+                break                      # (adaptation oscillates around 0.5; do not wait for ever)
+            acc = hmc_acceptance(step)
+            step += 1
+            equil += 1
+        step, dt, ns_total, launches, kms, st = timed(args.steps, step)
     else:
-        world_seen = 1
+        dt, launches, kms, st = dt_w, launches_w, kms_w, st_w
+    world_seen = dist.get_world_size() if dist is not None else 1
 
-    launches, kms = eng.timing()
-    st = eng.stats()
     # one more block outside the timed region, read before gen_mc_params zeroes the counters: the per-replica acceptance
     # ratios and U, V the metric's definition asks to see next to the rate (SURVEY.md §8d)
     eng.set_step(step)
@@ -197,21 +224,45 @@ def main():
         phmc = 1.0 - 0.125 - 0.125
         evals_alg = 0.125 + 0.125 + phmc * 9.0                             # EVALS = PPOS + PVOL + PHMC (NSTPS + 1) = 7.0
         bytes_per_sweep = 48.0 * natoms + 24.0 * natoms * phmc             # SURVEY.md §8d compulsory HBM bytes
-        k_avg_s = (kms / max(launches, 1)) * 1e-3
         sweeps_per_launch = ns * mod
-        achieved_gbs = bytes_per_sweep * sweeps_per_launch / k_avg_s / 1e9
-        evals = st[:, 0].sum()
-        mean_pairs = st[:, 3].sum() / max(st[:, 2].sum(), 1.0)
-        tf_exec = evals * mean_pairs * FLOP_PER_PAIR / (kms * 1e-3) / 1e12
-        flop_alg_launch = evals_alg * sweeps_per_launch * mean_pairs * FLOP_PER_PAIR
-        tf_alg = flop_alg_launch / k_avg_s / 1e12
+
+        def numbers(dt_, launches_, kms_, st_):
+            """rate, kernel time and roofline figures of one timed region of args.steps cycles"""
+            k_avg_s = (kms_ / max(launches_, 1)) * 1e-3
+            evals = st_[:, 0].sum()
+            mean_pairs = st_[:, 3].sum() / max(st_[:, 2].sum(), 1.0)
+            flop_alg_launch = evals_alg * sweeps_per_launch * mean_pairs * FLOP_PER_PAIR
+            blk_ms = st_[:, 4] / np.maximum(st_[:, 6], 1.0) * 1e-5          # per slot: mean time of its blocks (100 MHz ticks -> ms)
+            return {'value': ns_total * mod * args.steps / dt_, 'ms_per_step': dt_ / args.steps * 1e3,
+                    'kernel_avg_ms': k_avg_s * 1e3, 'launches': launches_,
+                    'achieved': flop_alg_launch / k_avg_s / 1e12, 'frac': flop_alg_launch / k_avg_s / 1e12 / FP64_VEC_PEAK_TF,
+                    'algorithmic_flop_per_launch': flop_alg_launch,
+                    'executed': evals * mean_pairs * FLOP_PER_PAIR / (kms_ * 1e-3) / 1e12,
+                    'frac_executed': evals * mean_pairs * FLOP_PER_PAIR / (kms_ * 1e-3) / 1e12 / FP64_VEC_PEAK_TF,
+                    'evals_per_sweep': evals / (ns * mod * args.steps), 'mean_pairs_per_eval': mean_pairs,
+                    'list_rebuilds_per_sweep': st_[:, 1].sum() / (ns * mod * args.steps),
+                    'hbm_gbs_algorithmic': bytes_per_sweep * sweeps_per_launch / k_avg_s / 1e9,
+                    # a launch lasts as long as its slowest replica: mean and maximum over the slots of their mean block time
+                    'slot_block_ms_mean': float(blk_ms.mean()), 'slot_block_ms_max': float(blk_ms.max()),
+                    'clusters_on_one_xcd': float(st_[:, 5].sum() / max(st_[:, 6].sum(), 1.0)) if eng.cus_per_replica > 1 else None}
+
+        win = numbers(dt_w, launches_w, kms_w, st_w)
+        sus = numbers(dt, launches, kms, st) if args.equil > 0 else win
         prof = measured_profile(args.config if not custom else None, ns, mod)
         grid = '%dx%d PxT grid%s' % (npn, tn, '' if world == 1 else ' over %d GPUs' % world)
         metric = 'MC sweeps/sec (whole node), %s %d^3 cells, %s' % (el, sz, grid)
         out = {
-            'metric': metric, 'value': value, 'unit': 'sweeps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
+            # value = the SUSTAINED rate: `steps` timed cycles of equilibrated chains (HMC accepting about half its trajectories, step
+            # sizes adapted).  `window` = the same number of cycles timed right after `warmup` cycles from the lattice start, where
+            # trajectories are still short and lists are rebuilt less often: what rounds 1 and 2 reported as value.
+            'metric': metric, 'value': sus['value'], 'unit': 'sweeps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': sus['ms_per_step'], 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
+            'equilibration_cycles': equil, 'timed_from_cycle': step - args.steps if args.equil > 0 else args.warmup,
+            'window': {k: win[k] for k in ('value', 'ms_per_step', 'kernel_avg_ms', 'frac', 'frac_executed', 'evals_per_sweep',
+                                           'list_rebuilds_per_sweep', 'slot_block_ms_mean', 'slot_block_ms_max')},
+            'sustained': {k: sus[k] for k in ('value', 'ms_per_step', 'kernel_avg_ms', 'frac', 'frac_executed', 'evals_per_sweep',
+                                              'list_rebuilds_per_sweep', 'slot_block_ms_mean', 'slot_block_ms_max')},
             'config': {'workload': '%s; %s %d^3 cells (%d atoms), %d replicas on rank 0 (%d in all), MOD=%d, %s PMC 0.125 / VMC '
                                    '0.125 / HMC 0.75 x 8 steps, outputs off' % (desc, el, sz, natoms, ns, ns_total, mod,
                                                                                'iterative' if args.iterative else 'bulk'),
@@ -220,21 +271,22 @@ def main():
                        'parallelism': ('rows/gpu' if not split else 'slots/gpu, split-row exchange over %s' % backend),
                        'world_size_seen_by_backend': world_seen, 'backend': backend},
             # The binding roofline: the working set is LDS-resident, so the ceiling is fp64 vector issue.
-            # achieved = algorithmic flops per launch (7.0 evaluations per sweep x measured interacting pairs x 40 flop) / the
-            # kernel's HIP-event time; traffic = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/).
-            'roofline': {'bound': 'fp64-valu', 'achieved': tf_alg, 'peak': FP64_VEC_PEAK_TF, 'unit': 'TFLOP/s',
-                         'frac': tf_alg / FP64_VEC_PEAK_TF, 'traffic': prof.get('traffic'),
-                         'kernel': 'nm_block_kernel', 'kernel_avg_ms': k_avg_s * 1e3, 'launches': launches,
-                         'algorithmic_flop_per_launch': flop_alg_launch, 'algorithmic_evals_per_sweep': evals_alg,
-                         'executed': tf_exec, 'evals_per_sweep': evals / (ns * mod * args.steps),
-                         'mean_pairs_per_eval': mean_pairs, 'flop_per_pair': FLOP_PER_PAIR,
-                         'list_rebuilds_per_sweep': st[:, 1].sum() / (ns * mod * args.steps),
+            # achieved = ALGORITHMIC flops per launch (7.0 evaluations per sweep x measured interacting pairs x 40 flop) / the
+            # kernel's HIP-event time over the timed (sustained) region; executed = what the kernel actually evaluated (it keeps forces
+            # across moves: ~6.26 evaluations per sweep); traffic = HBM bytes per launch from the committed rocprofv3 PMC passes.
+            'roofline': {'bound': 'fp64-valu', 'achieved': sus['achieved'], 'peak': FP64_VEC_PEAK_TF, 'unit': 'TFLOP/s',
+                         'frac': sus['frac'], 'traffic': prof.get('traffic'),
+                         'kernel': 'nm_block_kernel', 'kernel_avg_ms': sus['kernel_avg_ms'], 'launches': sus['launches'],
+                         'algorithmic_flop_per_launch': sus['algorithmic_flop_per_launch'], 'algorithmic_evals_per_sweep': evals_alg,
+                         'executed': sus['executed'], 'frac_executed': sus['frac_executed'], 'evals_per_sweep': sus['evals_per_sweep'],
+                         'mean_pairs_per_eval': sus['mean_pairs_per_eval'], 'flop_per_pair': FLOP_PER_PAIR,
+                         'list_rebuilds_per_sweep': sus['list_rebuilds_per_sweep'],
                          'valu_active_share': prof.get('valu_active_share'), 'profile': prof.get('source'),
-                         'profile_commit': prof.get('commit'),
+                         'profile_commit': prof.get('commit'), 'clusters_on_one_xcd': sus['clusters_on_one_xcd'],
                          'cus_per_replica': eng.cus_per_replica, 'cus_occupied': min(ns * eng.cus_per_replica, 256), 'cus_total': 256},
             # the HBM line the contract asks for: algorithmic bytes (48 N + 24 N PHMC per sweep) / kernel time, << 1 % by design
-            'roofline_hbm': {'bound': 'hbm', 'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                             'frac': achieved_gbs / HBM_PEAK_GBS, 'traffic': prof.get('traffic'),
+            'roofline_hbm': {'bound': 'hbm', 'achieved': sus['hbm_gbs_algorithmic'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'frac': sus['hbm_gbs_algorithmic'] / HBM_PEAK_GBS, 'traffic': prof.get('traffic'),
                              'algorithmic_bytes_per_launch': bytes_per_sweep * sweeps_per_launch},
         }
         out['replicas'] = {'note': 'rank 0, block after the timed region, slot k = i*NT + j (pressure i, temperature j)',
@@ -243,8 +295,8 @@ def main():
                            'accept_hmc': [round(float(a), 3) for a in last[:, 16]],
                            'pe_per_atom': [round(float(a) / natoms, 4) for a in last[:, 1]],
                            'vol_per_atom': [round(float(a) / natoms, 4) for a in last[:, 4]]}
-        if not args.no_cpu and not args.iterative:  # (the CPU legs time bulk moves)
-            out['cpu_baseline'] = cpu_baseline(eng, natoms, el, mod, T, tn, k0, args.cpu_seconds)
+        if not args.no_cpu:
+            out['cpu_baseline'] = cpu_baseline(eng, natoms, el, mod, T, tn, k0, args.cpu_seconds, bulk=not args.iterative)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -260,8 +312,13 @@ def measured_profile(config, ns, mod):
     workloads without a committed profile."""
     if config is None:
         return {}
-    f = os.path.join(ROOT, 'profiles', 'r02_pmc_block_kernel_%s.json' % config)
-    if not os.path.isfile(f):
+    f = None
+    for rnd in ('r03', 'r02'):   # this round's passes; an older round's file is still labelled with the commit it belongs to
+        g = os.path.join(ROOT, 'profiles', '%s_pmc_block_kernel_%s.json' % (rnd, config))
+        if os.path.isfile(g):
+            f = g
+            break
+    if f is None:
         return {}
     d = json.load(open(f))
     meta = d.get('_meta', {})
@@ -277,7 +334,7 @@ def measured_profile(config, ns, mod):
     return out
 
 
-def cpu_baseline(eng, natoms, el, mod, T, tn, k0, seconds):
+def cpu_baseline(eng, natoms, el, mod, T, tn, k0, seconds, bulk=True):
     """the oracle (C restatement of the same path, kind "port": the reference's own CPU path needs a LAMMPS build that is neither
     in its tree nor in this image) timed on the host cores on the engine's post-warm-up states: (i) ONE thread on a bounded
     sample of the replicas, (ii) OpenMP over replicas on all cores, each for about `seconds` of wall time"""
@@ -295,7 +352,7 @@ def cpu_baseline(eng, natoms, el, mod, T, tn, k0, seconds):
     cores = min(cores, ns)  # one replica per thread: more threads than replicas would idle
     kw = dict(units=1, mass=lattice.MASS['Al'], pot=1) if el == 'Al' else {}
     tq = np.tile(T.astype(np.float64), (ns + tn - 1) // tn + 1)[(k0 % tn):(k0 % tn) + ns]
-    common = dict(natoms=natoms, nstps=8, bulk=True, ppos=0.125, pvol=0.125, lat=lattice.LAT[el][1], seed=256, **kw)
+    common = dict(natoms=natoms, nstps=8, bulk=bulk, ppos=0.125, pvol=0.125, lat=lattice.LAT[el][1], seed=256, **kw)
 
     def leg(sel, nthreads, mod_leg, budget):
         xs, vs, bs = x[sel].copy(), v[sel].copy(), box[sel].copy()

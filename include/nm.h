@@ -41,7 +41,10 @@ extern "C" {
 
 #define NM_THERMO_COLS 17     /* temp pe ke virial vol dx dv dt ntp nap ntv nav nth nah ap av ah (remcmc:208) */
 #define NM_TRACE_COLS 4       /* branch (0 bulk PMC, 1 VMC, 2 HMC, 3 iter PMC), accepted, criterion, U after */
-#define NM_STATS_COLS 4       /* evaluations, list rebuilds, energy evaluations, sum of interacting pairs over those */
+#define NM_STATS_COLS 10      /* per slot: evaluations, list rebuilds, energy evaluations, sum of interacting pairs over those,
+                                 time of the slot's blocks (ticks of the chip's 100 MHz clock, kernel entry to exit of the replica's
+                                 first workgroup), blocks whose cluster handed over inside one XCD's L2, blocks run, HMC moves, longest neighbour-list
+                                 row built (a maximum, not a sum), list slots per atom of the kernel in use */
 
 typedef struct nm_ctx nm_ctx;
 
@@ -67,7 +70,9 @@ typedef struct nm_config {
 /* life cycle */
 int nm_create(const nm_config *cfg, nm_ctx **out);
 int nm_destroy(nm_ctx *ctx);
-const char *nm_last_error(const nm_ctx *ctx);  /* ctx may be NULL: error of the last failed nm_create */
+const char *nm_last_error(const nm_ctx *ctx);  /* ctx may be NULL: error of the last failed nm_create; empty after a call that returned NM_OK */
+const char *nm_create_note(const nm_ctx *ctx); /* not an error: what the residency probe of nm_create gave up (fewer workgroups per replica
+                                                  than asked for), and every block that was re-issued at a lower number later on        */
 int nm_nslots(const nm_ctx *ctx);              /* nrows*nt replicas held by this context               */
 int nm_natoms(const nm_ctx *ctx);
 int nm_cus_per_replica(const nm_ctx *ctx);     /* workgroups (CUs) cooperating on one replica: 1, 2, 4 ...  */
@@ -111,7 +116,13 @@ int nm_exchange(nm_ctx *ctx, int *nswaps);
 /* waits for everything enqueued on the context; reports replicas that left the supported regime */
 int nm_synchronize(nm_ctx *ctx);
 /* status[nslots]: 0, or the NM_ST_* bits that stopped the slot's last block.  A block that ends on an error leaves the slot's
-   x, v, box and thermo scalars as they were when it started (the reference's LAMMPS would have aborted the process). */
+   x, v, box and thermo scalars as they were when it started (the reference's LAMMPS would have aborted the process), and nothing
+   queued behind it (blocks, nm_adapt, nm_exchange) runs until the host has looked: the next nm_synchronize / nm_get_* / nm_set_*
+   - re-issues the failed block and everything queued behind it with fewer workgroups per replica when the reason was the launch
+     itself (NM_ST_NOT_RESIDENT, NM_ST_SYNC_TIMEOUT: the analogue of Dask retrying a failed task, remcmc:921-922), notes that in
+     nm_create_note and returns NM_OK;
+   - otherwise returns NM_ERR_STATE once, with the reason in nm_last_error; the bits stay readable here until the next block and the
+     context remains usable (e.g. after nm_set_state of a configuration that fits). */
 #define NM_ST_LIST_OVERFLOW 1   /* more neighbours within rc + skin than list slots                           */
 #define NM_ST_BOX_TOO_SMALL 2   /* box edge < 2 rc: outside the minimum-image regime                          */
 #define NM_ST_TAPE_EXHAUSTED 4  /* test-only rng tape too short                                               */

@@ -12,10 +12,10 @@ c_int_p = C.POINTER(C.c_int)
 
 NM_OK, NM_ERR_ARG, NM_ERR_HIP, NM_ERR_STATE, NM_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 NM_EL_LJ, NM_EL_AL = 0, 1
-NM_THERMO_COLS, NM_TRACE_COLS, NM_STATS_COLS = 17, 4, 4
+NM_THERMO_COLS, NM_TRACE_COLS, NM_STATS_COLS = 17, 4, 10
 
 # every symbol include/nm.h declares (tests check that the library exports all of them)
-SYMBOLS = ('nm_create', 'nm_destroy', 'nm_last_error', 'nm_nslots', 'nm_natoms', 'nm_cus_per_replica', 'nm_get_const',
+SYMBOLS = ('nm_create', 'nm_destroy', 'nm_last_error', 'nm_create_note', 'nm_nslots', 'nm_natoms', 'nm_cus_per_replica', 'nm_get_const',
            'nm_set_state', 'nm_get_state', 'nm_init_lattice', 'nm_lattice_state', 'nm_set_thermo', 'nm_set_step', 'nm_run_md', 'nm_run_block', 'nm_get_thermo', 'nm_adapt',
            'nm_exchange', 'nm_synchronize', 'nm_get_status', 'nm_format_thrm', 'nm_format_traj', 'nm_append_outputs', 'nm_timing_reset', 'nm_timing_get', 'nm_stats_get', 'nm_eval',
            'nm_set_rng_tape', 'nm_set_exchange_tape', 'nm_set_trace', 'nm_get_trace', 'nm_get_perm', 'nm_set_counters',
@@ -53,6 +53,8 @@ def load():
     L.nm_destroy.argtypes = [vp]
     L.nm_last_error.restype = C.c_char_p
     L.nm_last_error.argtypes = [vp]
+    L.nm_create_note.restype = C.c_char_p
+    L.nm_create_note.argtypes = [vp]
     L.nm_nslots.argtypes = [vp]
     L.nm_natoms.argtypes = [vp]
     L.nm_cus_per_replica.argtypes = [vp]
@@ -86,7 +88,7 @@ def load():
     L.nm_set_counters.argtypes = [vp, c_double_p, c_float_p]
     L.nm_get_exchange_crit.argtypes = [vp, c_double_p, C.c_int]
     for s in SYMBOLS:
-        if s != 'nm_last_error':
+        if s not in ('nm_last_error', 'nm_create_note'):
             getattr(L, s).restype = C.c_int
     L.nm_distr_histograms.restype = C.c_int
     L.nm_distr_histograms.argtypes = [C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, C.c_int, c_double_p, C.c_int, c_double_p,

@@ -40,7 +40,9 @@ typedef Cfg<512, 1, 864, 160, unsigned short, false, true> CfgMid;     // N <= 8
 typedef Cfg<512, 2, 864, 160, unsigned short, false, true> CfgMidQ4;
 // 8 workgroups per replica: 108 own atoms, whose list rows (16-bit, 35 KB) fit in LDS once the saved velocities moved to the spill
 typedef Cfg<512, 4, 864, 160, unsigned short, true, true, 0, 108, false> CfgMidQ8;
-typedef Cfg<512, 1, 2048, 160, unsigned short, false, false> CfgLarge; // N <= 2048: saved copies spill to HBM as well
+// N <= 2048: saved copies spill to HBM as well.  224 list slots: the list lives in HBM, so slots are cheap, and at skin 0.6 the dense
+// crystals (P* = 8: 140 neighbours inside 3.1, the next shell of 36 just beyond) came within ~10 % of the 160 there were
+typedef Cfg<512, 1, 2048, 224, unsigned short, false, false> CfgLarge;
 
 thread_local std::string g_create_error;
 
@@ -63,8 +65,16 @@ struct nm_ctx {
     // device
     double *d_x, *d_v, *d_box, *d_steps, *d_therm, *d_count, *d_et, *d_pf, *d_tq, *d_stats;
     float *d_ratio;
-    int *d_slot2buf, *d_status, *d_nswaps;
+    int *d_slot2buf, *d_status, *d_status_acc, *d_halt, *d_rerun, *d_nswaps;
     unsigned int *d_census; // residency census of cluster launches (nm_kernels.h)
+    // Calls queued on the stream since the host last looked at the outcome (settle): if a block of them stopped because its
+    // cluster grid was not resident or a hand-over timed out, nothing after it has run (KParams::halt) and the same calls are
+    // issued again with fewer workgroups per replica.
+    struct Op { int kind, arg, trace; uint32_t step, launch_id; };
+    std::vector<Op> journal;
+    int heals = 0;              // blocks re-issued at a lower Q so far
+    int cluster_launches = 0;   // (NM_INJECT_CENSUS counts these)
+    std::string note;           // what nm_create's residency probe and later re-issues had to give up (nm_create_note)
     double *d_tape, *d_xtape, *d_trace, *d_xcrit, *d_evalU, *d_evalW, *d_evalF, *d_aux;
     int *d_tape_off;
     void *d_nbr;
@@ -102,6 +112,14 @@ int fail(nm_ctx *c, int code, const std::string &msg)
 template <class T>
 hipError_t dalloc(T **p, size_t n) { return hipMalloc((void **)p, (n ? n : 1) * sizeof(T)); }
 
+// test-only environment hooks (NM_ASSUME_CUS, NM_INJECT_OVERFLOW, NM_INJECT_CENSUS) are honoured only under NM_TESTING=1, so that a
+// stray variable cannot change Q or stop a production run
+bool testing()
+{
+    const char *e = std::getenv("NM_TESTING");
+    return e && std::atoi(e) != 0;
+}
+
 void fill_params(const nm_ctx *c, KParams &p)
 {
     std::memset(&p, 0, sizeof p);
@@ -127,10 +145,12 @@ void fill_params(const nm_ctx *c, KParams &p)
     p.tline = c->d_tline;
     if (const char *e = std::getenv("NM_DBG")) p.dbg = std::atoi(e);
     p.inj_rebuild = -1; p.inj_q = 0;
-    if (const char *e = std::getenv("NM_INJECT_OVERFLOW")) { // tests of the error path only
+    const char *e = testing() ? std::getenv("NM_INJECT_OVERFLOW") : nullptr; // tests of the error path only
+    if (e) {
         int n = -1, q = 0;
         if (std::sscanf(e, "%d,%d", &n, &q) >= 1) { p.inj_rebuild = n; p.inj_q = q; }
     }
+    p.status_acc = c->d_status_acc; p.halt = c->d_halt; p.rerun_mask = nullptr; p.inj_census = 0;
 }
 
 template <class C>
@@ -208,26 +228,215 @@ void harvest(nm_ctx *c, EvPair &e)
     e.used = false;
 }
 
+std::string status_text(const nm_ctx *c, int k, int bits)
+{
+    char buf[640];
+    std::snprintf(buf, sizeof buf,
+                  "replica slot %d (global %d) left the supported regime:%s%s%s%s%s%s", k, c->slot0 + k,
+                  (bits & ST_LIST_OVERFLOW) ? " neighbour list overflow;" : "",
+                  (bits & ST_BOX_TOO_SMALL) ? " box edge < 2*rc (minimum image invalid);" : "",
+                  (bits & ST_TAPE_EXHAUSTED) ? " rng tape exhausted;" : "",
+                  (bits & ST_NONFINITE) ? " non-finite energy;" : "",
+                  (bits & ST_SYNC_TIMEOUT) ? " cluster hand-off timed out (workgroups not co-resident?);" : "",
+                  (bits & ST_NOT_RESIDENT) ? " the launch's workgroups were not resident together (CUs taken by another process, stream or a CU "
+                                             "mask): nothing was changed;" : "");
+    return buf;
+}
+
+enum : int { OP_BLOCK = 0, OP_ADAPT = 1, OP_EXCHANGE = 2, OP_MD = 3 };
+
+// ---- the queued calls (nm_run_block, nm_run_md, nm_adapt, nm_exchange) as stream operations; issued by the API call and, after a
+// block had to be given up, again by settle()
+int check_status(nm_ctx *c);
+
+int issue_block(nm_ctx *c, int kind, int arg, uint32_t step, int trace, const int *d_mask, bool timed)
+{
+    if (c->journal.size() > 4096 && !d_mask) { // a caller that never looks: bound the journal
+        const int rc = check_status(c);
+        if (rc) return rc;
+    }
+    ++c->launch_id;
+    KParams p;
+    const uint32_t keep = c->step;
+    c->step = step;
+    fill_params(c, p);
+    c->step = keep;
+    p.rerun_mask = d_mask;
+    if (kind == OP_MD) { p.mod = 1; p.md_mode = 1; p.nstps = arg; p.tape = nullptr; }
+    else {
+        p.mod = arg;
+        if (trace) {
+            const size_t need = (size_t)c->nslots * arg * NM_TRACE_COLS;
+            if (need > c->trace_cap) {
+                if (c->d_trace) HIPCHK(c, hipFree(c->d_trace));
+                c->d_trace = nullptr;
+                HIPCHK(c, dalloc(&c->d_trace, need));
+                c->trace_cap = need;
+            }
+            if (!d_mask) HIPCHK(c, hipMemsetAsync(c->d_trace, 0, need * sizeof(double), c->stream));
+            p.trace = c->d_trace;
+            c->trace_mod = arg;
+        }
+    }
+    if (testing())
+        if (const char *e = std::getenv("NM_INJECT_CENSUS")) // "n": the context's n-th cluster launch fails its residency census
+            if (c->cus > 1 && std::atoi(e) == c->cluster_launches) p.inj_census = 1;
+    if (c->cus > 1) ++c->cluster_launches;
+    // status[] holds the bits of the LAST launch (status_acc[] everything since the host last looked); a launch that finds the halt
+    // word armed does nothing, and the memset in front of it must not wipe the failed block's bits: they are in status_acc[]
+    HIPCHK(c, hipMemsetAsync(c->d_status, 0, sizeof(int) * c->nslots, c->stream));
+    if (timed) {
+        EvPair &e = c->ev[c->ev_next];
+        harvest(c, e);
+        HIPCHK(c, hipEventRecord(e.a, c->stream));
+        HIPCHK(c, launch_kind(c, p));
+        HIPCHK(c, hipEventRecord(e.b, c->stream));
+        e.used = true;
+        c->ev_next = (c->ev_next + 1) % (int)c->ev.size();
+    } else HIPCHK(c, launch_kind(c, p));
+    c->journal.push_back({ kind, arg, trace, step, c->launch_id });
+    return NM_OK;
+}
+
+int issue_adapt(nm_ctx *c)
+{
+    hipLaunchKernelGGL(nm_adapt_kernel, dim3((c->nslots + 63) / 64), dim3(64), 0, c->stream, c->nslots, c->d_slot2buf,
+                       c->d_steps, c->d_count, c->d_ratio, c->d_halt);
+    HIPCHK(c, hipGetLastError());
+    c->journal.push_back({ OP_ADAPT, 0, 0, 0u, 0u });
+    return NM_OK;
+}
+
+int issue_exchange(nm_ctx *c, uint32_t step)
+{
+    HIPCHK(c, hipMemsetAsync(c->d_nswaps, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(nm_exchange_kernel, dim3((c->cfg.nrows + 63) / 64), dim3(64), 0, c->stream, c->cfg.nrows, c->cfg.nt,
+                       c->cfg.row0, c->cfg.seed, step, c->d_slot2buf, c->d_therm, c->d_et, c->d_pf,
+                       c->xtape_n ? c->d_xtape : nullptr, c->d_xcrit, c->d_nswaps, c->d_halt);
+    HIPCHK(c, hipGetLastError());
+    c->journal.push_back({ OP_EXCHANGE, 0, 0, step, 0u });
+    return NM_OK;
+}
+
+// Workgroups per replica.  A cluster spins on its peers, so every workgroup of the grid must be resident at once.  The candidates
+// are the Q <= qmax for which the occupancy query admits the whole grid (workgroups per CU x CUs); the first one whose grid
+// actually gathers in a residency census (nm_probe_kernel: the block kernel's launch shape, census only, nm_kernels.h) is taken,
+// so a masked or busy CU lowers Q instead of stalling every block.  Leaves c->cus set; 1 when no cluster gathers.
+int pick_q(nm_ctx *c, int qmax, std::string &note)
+{
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, c->cfg.device));
+    int cu = prop.multiProcessorCount;
+    if (testing())
+        if (const char *e = std::getenv("NM_ASSUME_CUS")) { const int v = std::atoi(e); if (v > 0) cu = v; } // tests of the fallback
+    const int maxq = c->kind == 0 ? (c->pot == 0 ? 8 : 4) : c->kind == 1 ? 8 : 2; // own-atom ranges the instantiated thread mappings cover
+    c->cus = 1;
+    for (int qq : { 8, 4, 2 }) {
+        if (qq > maxq || qq > qmax) continue;
+        const int per_cu = blocks_per_cu_kind(c->kind, c->pot, qq);
+        if ((long)c->nslots * qq > (long)per_cu * cu) continue;
+        c->cus = qq; // probe: does the grid of this Q gather?
+        KParams p;
+        fill_params(c, p);
+        p.status_acc = nullptr; p.halt = nullptr;
+        HIPCHK(c, hipMemsetAsync(c->d_status, 0, sizeof(int) * c->nslots, c->stream));
+        HIPCHK(c, probe_kind(c, p));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::vector<int> st((size_t)c->nslots);
+        HIPCHK(c, hipMemcpy(st.data(), c->d_status, sizeof(int) * c->nslots, hipMemcpyDeviceToHost));
+        bool ok = true;
+        for (int v : st) ok = ok && !(v & ST_NOT_RESIDENT);
+        HIPCHK(c, hipMemset(c->d_status, 0, sizeof(int) * c->nslots));
+        if (ok) return NM_OK;
+        char buf[200];
+        std::snprintf(buf, sizeof buf, "%d workgroups per replica (%d in all) did not gather on this device; falling back. ", qq, c->nslots * qq);
+        note += buf;
+        c->cus = 1;
+    }
+    return NM_OK;
+}
+
+// the buffers whose size depends on the workgroups per replica: the per-workgroup spill and the hand-over granules
+int alloc_cluster_buffers(nm_ctx *c)
+{
+    if (c->d_aux) { HIPCHK(c, hipFree(c->d_aux)); c->d_aux = nullptr; }
+    if (c->d_xbuf) { HIPCHK(c, hipFree(c->d_xbuf)); c->d_xbuf = nullptr; }
+    const size_t ns = c->nslots;
+    if (c->kind == 0) c->aux_doubles = CfgSmall::AUX_DOUBLES;
+    else if (c->kind == 1) { c->aux_doubles = c->cus == 8 ? CfgMidQ8::AUX_DOUBLES : CfgMid::AUX_DOUBLES; c->lds_bytes = c->cus == 8 ? CfgMidQ8::LDS_BYTES : CfgMid::LDS_BYTES; }
+    else c->aux_doubles = CfgLarge::AUX_DOUBLES;
+    if (c->aux_doubles) HIPCHK(c, dalloc(&c->d_aux, ns * c->cus * c->aux_doubles));
+    const size_t xbd = c->kind == 0 ? CfgSmall::XBUF_DOUBLES : c->kind == 1 ? CfgMid::XBUF_DOUBLES : CfgLarge::XBUF_DOUBLES;
+    if (c->cus > 1) { HIPCHK(c, dalloc(&c->d_xbuf, ns * 2 * xbd)); HIPCHK(c, hipMemset(c->d_xbuf, 0, ns * 2 * xbd * sizeof(double))); }
+    return NM_OK;
+}
+
+// The outcome of everything queued so far; the stream has been synchronised by the caller.  A block that stopped because its
+// cluster grid was not resident (NM_ST_NOT_RESIDENT: nothing was touched) or a hand-over timed out (NM_ST_SYNC_TIMEOUT: the
+// replicas concerned are as they were at the block's start) armed the halt word, so nothing queued behind it has run either
+// (the reference's analogue is Dask retrying a failed gen_sample task, remcmc:921-922): the context drops to the next lower
+// number of workgroups per replica that gathers and issues the same calls again — the failed block for the replicas that did
+// not complete it, everything behind it as it was.  Any other status is the caller's to deal with: NM_ERR_STATE once, with
+// the reason; the replicas' state is that of the failed block's start and the context stays usable.
+int settle(nm_ctx *c)
+{
+    for (int round = 0; round < 4; ++round) {
+        int halt = 0;
+        HIPCHK(c, hipMemcpy(&halt, c->d_halt, sizeof(int), hipMemcpyDeviceToHost));
+        std::vector<int> st((size_t)c->nslots);
+        HIPCHK(c, hipMemcpy(st.data(), c->d_status_acc, sizeof(int) * c->nslots, hipMemcpyDeviceToHost));
+        int any = 0;
+        for (int v : st) any |= v;
+        if (!halt && !any) { c->journal.clear(); return NM_OK; }
+        const int healable = ST_NOT_RESIDENT | ST_SYNC_TIMEOUT;
+        size_t at = c->journal.size();
+        for (size_t k = 0; k < c->journal.size(); ++k)
+            if ((c->journal[k].kind == OP_BLOCK || c->journal[k].kind == OP_MD) && (int)c->journal[k].launch_id == halt) { at = k; break; }
+        if (halt && !(any & ~healable) && c->cus > 1 && at < c->journal.size()) {
+            // ---- re-issue at a lower Q
+            const int q_old = c->cus;
+            std::string why;
+            int rc = pick_q(c, q_old / 2, why);
+            if (rc) return rc;
+            if ((rc = alloc_cluster_buffers(c))) return rc;
+            std::vector<int> mask((size_t)c->nslots);
+            for (int k = 0; k < c->nslots; ++k) mask[k] = st[k] ? 1 : 0;
+            HIPCHK(c, hipMemcpy(c->d_rerun, mask.data(), sizeof(int) * c->nslots, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemset(c->d_status_acc, 0, sizeof(int) * c->nslots));
+            HIPCHK(c, hipMemset(c->d_halt, 0, sizeof(int)));
+            char buf[256];
+            std::snprintf(buf, sizeof buf, "block of step %u stopped at %d workgroups per replica (%s); re-issued at %d. %s",
+                          c->journal[at].step, q_old, (any & ST_NOT_RESIDENT) ? "grid not resident" : "hand-over timed out", c->cus, why.c_str());
+            c->note += buf;
+            ++c->heals;
+            std::vector<nm_ctx::Op> todo(c->journal.begin() + at, c->journal.end());
+            c->journal.clear();
+            for (size_t k = 0; k < todo.size(); ++k) {
+                const nm_ctx::Op &o = todo[k];
+                if (o.kind == OP_BLOCK || o.kind == OP_MD) rc = issue_block(c, o.kind, o.arg, o.step, o.trace, k == 0 ? c->d_rerun : nullptr, false);
+                else if (o.kind == OP_ADAPT) rc = issue_adapt(c);
+                else rc = issue_exchange(c, o.step);
+                if (rc) return rc;
+            }
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            continue; // look at the outcome of the re-issue
+        }
+        // ---- not curable here: report once, leave the context usable
+        c->journal.clear();
+        HIPCHK(c, hipMemcpy(c->d_status, st.data(), sizeof(int) * c->nslots, hipMemcpyHostToDevice)); // nm_get_status: what stopped which slot
+        HIPCHK(c, hipMemset(c->d_status_acc, 0, sizeof(int) * c->nslots));
+        HIPCHK(c, hipMemset(c->d_halt, 0, sizeof(int)));
+        for (int k = 0; k < c->nslots; ++k)
+            if (st[k]) return fail(c, NM_ERR_STATE, status_text(c, k, st[k]));
+        return fail(c, NM_ERR_STATE, "a block stopped on an error that left no status bits");
+    }
+    return fail(c, NM_ERR_STATE, "a block could not be completed at any number of workgroups per replica");
+}
+
 int check_status(nm_ctx *c)
 {
-    std::vector<int> st(c->nslots);
-    if (hipMemcpy(st.data(), c->d_status, sizeof(int) * c->nslots, hipMemcpyDeviceToHost) != hipSuccess)
-        return fail(c, NM_ERR_HIP, "status readback failed");
-    for (int k = 0; k < c->nslots; ++k)
-        if (st[k]) {
-            char buf[512];
-            std::snprintf(buf, sizeof buf,
-                          "replica slot %d (global %d) left the supported regime:%s%s%s%s%s%s", k, c->slot0 + k,
-                          (st[k] & ST_LIST_OVERFLOW) ? " neighbour list overflow;" : "",
-                          (st[k] & ST_BOX_TOO_SMALL) ? " box edge < 2*rc (minimum image invalid);" : "",
-                          (st[k] & ST_TAPE_EXHAUSTED) ? " rng tape exhausted;" : "",
-                          (st[k] & ST_NONFINITE) ? " non-finite energy;" : "",
-                          (st[k] & ST_SYNC_TIMEOUT) ? " cluster hand-off timed out (workgroups not co-resident?);" : "",
-                          (st[k] & ST_NOT_RESIDENT) ? " the launch's workgroups were not resident together (CUs taken by another process, stream or a CU "
-                                                      "mask): nothing was changed, re-issue the block or lower NM_CUS_PER_REPLICA;" : "");
-            return fail(c, NM_ERR_STATE, buf);
-        }
-    return NM_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return settle(c);
 }
 
 } // namespace
@@ -235,6 +444,7 @@ int check_status(nm_ctx *c)
 extern "C" {
 
 const char *nm_last_error(const nm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char *nm_create_note(const nm_ctx *ctx) { return ctx ? ctx->note.c_str() : ""; }
 int nm_nslots(const nm_ctx *ctx) { return ctx ? ctx->nslots : NM_ERR_ARG; }
 int nm_natoms(const nm_ctx *ctx) { return ctx ? ctx->N : NM_ERR_ARG; }
 int nm_cus_per_replica(const nm_ctx *ctx) { return ctx ? ctx->cus : NM_ERR_ARG; }
@@ -324,53 +534,28 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     } while (0)
     CHK(hipSetDevice(cfg->device));
     CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    // Workgroups per replica.  A cluster spins on its peers, so every workgroup of the grid must be resident at once.  The
-    // candidates are the Q for which the occupancy query admits the whole grid (workgroups per CU x CUs); the first one whose
-    // grid actually gathers in a residency census (nm_probe_kernel: the block kernel's launch shape, census only,
-    // nm_kernels.h) is taken, so a masked or busy CU lowers Q here instead of stalling every block.  Every later launch runs
-    // the same census and leaves with ST_NOT_RESIDENT, state untouched, if the grid does not gather.
-    c->cus = 1; c->d_xbuf = nullptr; c->launch_id = 0; c->d_census = nullptr;
+    c->cus = 1; c->d_xbuf = nullptr; c->d_aux = nullptr; c->launch_id = 0; c->d_census = nullptr;
+    c->d_status_acc = nullptr; c->d_halt = nullptr; c->d_rerun = nullptr;
     std::string note;
     {
-        hipDeviceProp_t prop;
-        CHK(hipGetDeviceProperties(&prop, cfg->device));
-        int cu = prop.multiProcessorCount;
-        if (const char *e = std::getenv("NM_ASSUME_CUS")) { const int v = std::atoi(e); if (v > 0) cu = v; } // tests of the fallback
         int want = 8;
         if (const char *e = std::getenv("NM_CUS_PER_REPLICA")) want = std::atoi(e);
-        const int maxq = c->kind == 0 ? (c->pot == 0 ? 8 : 4) : c->kind == 1 ? 8 : 2; // own-atom ranges the instantiated thread mappings cover
         CHK(dalloc(&c->d_census, 1));
         CHK(dalloc(&c->d_status, (size_t)c->nslots));
         CHK(hipMemset(c->d_status, 0, sizeof(int) * c->nslots));
+        CHK(dalloc(&c->d_status_acc, (size_t)c->nslots));
+        CHK(hipMemset(c->d_status_acc, 0, sizeof(int) * c->nslots));
+        CHK(dalloc(&c->d_rerun, (size_t)c->nslots));
+        CHK(dalloc(&c->d_halt, 1));
+        CHK(hipMemset(c->d_halt, 0, sizeof(int)));
         CHK(dalloc(&c->d_slot2buf, (size_t)c->nslots));
         {
             std::vector<int> ident((size_t)c->nslots);
             for (int k = 0; k < c->nslots; ++k) ident[k] = k;
             CHK(hipMemcpy(c->d_slot2buf, ident.data(), sizeof(int) * c->nslots, hipMemcpyHostToDevice));
         }
-        for (int qq : { 8, 4, 2 }) {
-            if (qq > maxq || want < qq) continue;
-            const int per_cu = blocks_per_cu_kind(c->kind, c->pot, qq);
-            if ((long)c->nslots * qq > (long)per_cu * cu) continue;
-            // probe: does the grid of this Q gather?
-            c->cus = qq;
-            KParams p;
-            fill_params(c, p);
-            CHK(probe_kind(c, p));
-            CHK(hipStreamSynchronize(c->stream));
-            std::vector<int> st((size_t)c->nslots);
-            CHK(hipMemcpy(st.data(), c->d_status, sizeof(int) * c->nslots, hipMemcpyDeviceToHost));
-            bool ok = true;
-            for (int v : st) ok = ok && !(v & ST_NOT_RESIDENT);
-            if (ok) break;
-            CHK(hipMemset(c->d_status, 0, sizeof(int) * c->nslots));
-            char buf[200];
-            std::snprintf(buf, sizeof buf, "nm_create: %d workgroups per replica (%d in all) did not gather on this device; falling back. ",
-                          qq, c->nslots * qq);
-            note += buf;
-            c->cus = 1;
-        }
-        if (c->kind == 1 && c->cus == 8) { c->aux_doubles = CfgMidQ8::AUX_DOUBLES; c->lds_bytes = CfgMidQ8::LDS_BYTES; }
+        if (pick_q(c, want, note) != NM_OK) { g_create_error = c->err; delete c; return NM_ERR_HIP; } // (workgroups per replica: see pick_q)
+        if (!note.empty()) note = "nm_create: " + note;
     }
     const size_t ns = c->nslots, n3 = (size_t)3 * c->N;
     CHK(dalloc(&c->d_x, ns * n3)); CHK(dalloc(&c->d_v, ns * n3));
@@ -390,11 +575,9 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
 #ifdef NM_PROF
     CHK(dalloc(&c->d_prof, ns * 16)); CHK(hipMemset(c->d_prof, 0, ns * 16 * sizeof(unsigned long long)));
 #endif
-    c->d_tape = nullptr; c->d_tape_off = nullptr; c->d_trace = nullptr; c->d_nbr = nullptr; c->d_aux = nullptr;
+    c->d_tape = nullptr; c->d_tape_off = nullptr; c->d_trace = nullptr; c->d_nbr = nullptr;
     if (nbr_elems) CHK(hipMalloc(&c->d_nbr, ns * 2 * nbr_elems * sizeof(unsigned short))); // two lists per slot (Cfg::LIST2)
-    if (c->aux_doubles) CHK(dalloc(&c->d_aux, ns * c->cus * c->aux_doubles));
-    const size_t xbd = c->kind == 0 ? CfgSmall::XBUF_DOUBLES : c->kind == 1 ? CfgMid::XBUF_DOUBLES : CfgLarge::XBUF_DOUBLES;
-    if (c->cus > 1) { CHK(dalloc(&c->d_xbuf, ns * 2 * xbd)); CHK(hipMemset(c->d_xbuf, 0, ns * 2 * xbd * sizeof(double))); }
+    if (alloc_cluster_buffers(c) != NM_OK) { g_create_error = c->err; delete c; return NM_ERR_HIP; }
     CHK(hipMemset(c->d_x, 0, ns * n3 * sizeof(double))); CHK(hipMemset(c->d_v, 0, ns * n3 * sizeof(double)));
     CHK(hipMemset(c->d_box, 0, ns * sizeof(double))); CHK(hipMemset(c->d_steps, 0, ns * 3 * sizeof(double)));
     CHK(hipMemset(c->d_therm, 0, ns * 5 * sizeof(double))); CHK(hipMemset(c->d_count, 0, ns * 6 * sizeof(double)));
@@ -423,7 +606,8 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     c->ev.resize(32);
     for (auto &e : c->ev) { CHK(hipEventCreate(&e.a)); CHK(hipEventCreate(&e.b)); e.used = false; }
 #undef CHK
-    c->err = note; // nm_last_error(ctx) after a successful nm_create: what the residency probe had to give up, if anything
+    c->err.clear();
+    c->note = note; // nm_create_note(ctx): what the residency probe had to give up, if anything
     *out = c;
     return NM_OK;
 }
@@ -436,7 +620,8 @@ int nm_destroy(nm_ctx *c)
     for (auto &e : c->ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     void *ptrs[] = { c->d_x, c->d_v, c->d_box, c->d_steps, c->d_therm, c->d_count, c->d_ratio, c->d_et, c->d_pf, c->d_tq,
                      c->d_stats, c->d_slot2buf, c->d_status, c->d_nswaps, c->d_evalU, c->d_evalW, c->d_evalF, c->d_xcrit,
-                     c->d_xtape, c->d_tape, c->d_tape_off, c->d_trace, c->d_nbr, c->d_aux, c->d_prof, c->d_tline, c->d_xbuf, c->d_census };
+                     c->d_xtape, c->d_tape, c->d_tape_off, c->d_trace, c->d_nbr, c->d_aux, c->d_prof, c->d_tline, c->d_xbuf, c->d_census,
+                     c->d_status_acc, c->d_halt, c->d_rerun };
     for (void *q : ptrs) if (q) hipFree(q);
     if (c->h_stage) hipHostFree(c->h_stage);
     hipStreamDestroy(c->stream);
@@ -462,7 +647,8 @@ int nm_set_step(nm_ctx *c, uint32_t step)
 static int slot_map(nm_ctx *c, std::vector<int> &m)
 {
     m.resize(c->nslots);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int rc = check_status(c); // everything queued has run (or has been re-issued) before state is read or replaced
+    if (rc) return rc;
     HIPCHK(c, hipMemcpy(m.data(), c->d_slot2buf, sizeof(int) * c->nslots, hipMemcpyDeviceToHost));
     return NM_OK;
 }
@@ -489,6 +675,22 @@ int nm_set_state(nm_ctx *c, int k0, int nk, const double *x, const double *v, co
     if (rc) return rc;
     const size_t n3 = (size_t)3 * c->N, ns = (size_t)c->nslots;
     const bool all = nk == c->nslots;
+    if (!all && nk <= 8) { // a few replicas (the split-row exchange re-seats the ones that swapped): copy just those
+        for (int q = 0; q < nk; ++q) {
+            const size_t bq = (size_t)m[k0 + q];
+            if (x) HIPCHK(c, hipMemcpyAsync(c->d_x + bq * n3, x + q * n3, n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            if (v) HIPCHK(c, hipMemcpyAsync(c->d_v + bq * n3, v + q * n3, n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            if (box) {
+                const double vol = std::pow(box[q], 3.0);
+                HIPCHK(c, hipMemcpyAsync(c->d_box + bq, box + q, sizeof(double), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->d_therm + 5 * bq + 4, &vol, sizeof(double), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream)); // (vol lives on this stack frame)
+            }
+            if (dxdvdt) HIPCHK(c, hipMemcpyAsync(c->d_steps + 3 * bq, dxdvdt + 3 * q, 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return NM_OK;
+    }
     // a partial range is merged into the device arrays: read them back first (set-up path, not timed)
     if ((rc = stage_reserve(c, 2 * ns * n3 + 9 * ns))) return rc;
     double *hx = c->h_stage, *hv = hx + ns * n3, *hb = hv + ns * n3, *hs = hb + ns, *ht = hs + 3 * ns;
@@ -571,6 +773,17 @@ int nm_get_state(nm_ctx *c, int k0, int nk, double *x, double *v, double *box, d
     int rc = slot_map(c, m);
     if (rc) return rc;
     const size_t n3 = (size_t)3 * c->N, ns = (size_t)c->nslots;
+    if (nk <= 8 && nk < c->nslots) { // a few replicas: copy just those
+        for (int q = 0; q < nk; ++q) {
+            const size_t bq = (size_t)m[k0 + q];
+            if (x) HIPCHK(c, hipMemcpyAsync(x + q * n3, c->d_x + bq * n3, n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            if (v) HIPCHK(c, hipMemcpyAsync(v + q * n3, c->d_v + bq * n3, n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            if (box) HIPCHK(c, hipMemcpyAsync(box + q, c->d_box + bq, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            if (dxdvdt) HIPCHK(c, hipMemcpyAsync(dxdvdt + 3 * q, c->d_steps + 3 * bq, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return NM_OK;
+    }
     if ((rc = stage_reserve(c, 2 * ns * n3 + 9 * ns))) return rc;
     double *hx = c->h_stage, *hv = hx + ns * n3, *hb = hv + ns * n3, *hs = hb + ns;
     if (x) HIPCHK(c, hipMemcpyAsync(hx, c->d_x, ns * n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -585,49 +798,21 @@ int nm_get_state(nm_ctx *c, int k0, int nk, double *x, double *v, double *box, d
         if (box) box[q] = hb[bq];
         if (dxdvdt) std::memcpy(dxdvdt + 3 * q, hs + 3 * bq, 3 * sizeof(double));
     }
-    return check_status(c);
+    return NM_OK; // (slot_map has looked at the outcome of everything queued)
 }
 
 int nm_run_block(nm_ctx *c, int mod)
 {
     if (!c || mod < 0) return fail(c, NM_ERR_ARG, "nm_run_block: bad argument");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    ++c->launch_id;
-    KParams p;
-    fill_params(c, p);
-    p.mod = mod;
-    if (c->trace_on) {
-        const size_t need = (size_t)c->nslots * mod * NM_TRACE_COLS;
-        if (need > c->trace_cap) {
-            if (c->d_trace) HIPCHK(c, hipFree(c->d_trace));
-            c->d_trace = nullptr;
-            HIPCHK(c, dalloc(&c->d_trace, need));
-            c->trace_cap = need;
-        }
-        HIPCHK(c, hipMemsetAsync(c->d_trace, 0, need * sizeof(double), c->stream));
-        p.trace = c->d_trace;
-        c->trace_mod = mod;
-    }
-    EvPair &e = c->ev[c->ev_next];
-    harvest(c, e);
-    HIPCHK(c, hipEventRecord(e.a, c->stream));
-    HIPCHK(c, launch_kind(c, p));
-    HIPCHK(c, hipEventRecord(e.b, c->stream));
-    e.used = true;
-    c->ev_next = (c->ev_next + 1) % (int)c->ev.size();
-    return NM_OK;
+    return issue_block(c, OP_BLOCK, mod, c->step, c->trace_on, nullptr, true);
 }
 
 int nm_run_md(nm_ctx *c, int nsteps)
 {
     if (!c || nsteps < 1) return fail(c, NM_ERR_ARG, "nm_run_md: bad argument");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    ++c->launch_id;
-    KParams p;
-    fill_params(c, p);
-    p.mod = 1; p.md_mode = 1; p.nstps = nsteps; p.tape = nullptr;
-    HIPCHK(c, launch_kind(c, p));
-    return NM_OK;
+    return issue_block(c, OP_MD, nsteps, c->step, 0, nullptr, false);
 }
 
 int nm_get_thermo(nm_ctx *c, double *rows)
@@ -652,17 +837,14 @@ int nm_get_thermo(nm_ctx *c, double *rows)
         for (int q = 0; q < 6; ++q) r[8 + q] = cn[6 * k + q];
         for (int q = 0; q < 3; ++q) r[14 + q] = (double)ra[3 * k + q];
     }
-    return check_status(c);
+    return NM_OK; // (slot_map has looked at the outcome of everything queued)
 }
 
 int nm_adapt(nm_ctx *c)
 {
     if (!c) return NM_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    hipLaunchKernelGGL(nm_adapt_kernel, dim3((c->nslots + 63) / 64), dim3(64), 0, c->stream, c->nslots, c->d_slot2buf,
-                       c->d_steps, c->d_count, c->d_ratio);
-    HIPCHK(c, hipGetLastError());
-    return NM_OK;
+    return issue_adapt(c);
 }
 
 int nm_exchange(nm_ctx *c, int *nswaps)
@@ -671,13 +853,10 @@ int nm_exchange(nm_ctx *c, int *nswaps)
     if (!c->whole_rows)
         return fail(c, NM_ERR_UNSUPPORTED, "nm_exchange: this context holds a partial pressure row; the sweep spans contexts (host exchange over RCCL)");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    HIPCHK(c, hipMemsetAsync(c->d_nswaps, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL(nm_exchange_kernel, dim3((c->cfg.nrows + 63) / 64), dim3(64), 0, c->stream, c->cfg.nrows, c->cfg.nt,
-                       c->cfg.row0, c->cfg.seed, c->step, c->d_slot2buf, c->d_therm, c->d_et, c->d_pf,
-                       c->xtape_n ? c->d_xtape : nullptr, c->d_xcrit, c->d_nswaps);
-    HIPCHK(c, hipGetLastError());
+    int rc = issue_exchange(c, c->step);
+    if (rc) return rc;
     if (nswaps) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if ((rc = check_status(c))) return rc;
         HIPCHK(c, hipMemcpy(nswaps, c->d_nswaps, sizeof(int), hipMemcpyDeviceToHost));
     }
     return NM_OK;
@@ -687,7 +866,6 @@ int nm_synchronize(nm_ctx *c)
 {
     if (!c) return NM_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_status(c);
 }
 
@@ -738,6 +916,17 @@ int nm_tline_get(nm_ctx *c, unsigned long long *out)
 }
 #endif
 #ifdef NM_PROF
+// diagnostic build only: out-of-range indices into the global spill / list arrays since the last call (counted and redirected by
+// the kernel, nm_kernels.h NM_CHECK_INDEX); scripts/check_bounds.py runs the large-cell parity cases under it
+int nm_prof_oob(nm_ctx *c, unsigned int *count)
+{
+    if (!c || !count) return NM_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyFromSymbol(count, HIP_SYMBOL(nm::nm_oob_count), sizeof(unsigned int)));
+    const unsigned int zero = 0;
+    HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(nm::nm_oob_count), &zero, sizeof(unsigned int)));
+    return NM_OK;
+}
 // diagnostic build only: cycle sums per section and slot, [nslots][16]
 int nm_prof_get(nm_ctx *c, unsigned long long *out, int reset)
 {
@@ -753,11 +942,14 @@ int nm_eval(nm_ctx *c, double *U, double *W, double *f)
 {
     if (!c || !U || !W) return fail(c, NM_ERR_ARG, "nm_eval: null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc0 = check_status(c); // (whatever is queued first: an evaluation is not re-issued)
+    if (rc0) return rc0;
     ++c->launch_id;
     KParams p;
     fill_params(c, p);
     p.eval_only = 1; p.tape = nullptr;
     p.evalU = c->d_evalU; p.evalW = c->d_evalW; p.evalF = f ? c->d_evalF : nullptr;
+    HIPCHK(c, hipMemsetAsync(c->d_status, 0, sizeof(int) * c->nslots, c->stream));
     HIPCHK(c, launch_kind(c, p));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const size_t ns = c->nslots;

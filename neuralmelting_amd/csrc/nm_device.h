@@ -52,7 +52,29 @@ struct KParams {
     uint32_t launch_id;            // distinguishes the granules of successive launches
     int plain_granules;            // 1: clusters found to sit on one XCD hand over through that XCD's L2 (plain stores); 0: always write-through
     unsigned int *census;          // cluster launches: arrival counter of the grid's workgroups (zeroed before the launch)
+    int *status_acc;               // per slot: status bits of every block since the host last looked (status[] holds the last launch's)
+    int *halt;                     // launch id of the first block that stopped on an error; later launches do nothing until the host
+                                   // has dealt with it (nm_api.hip settle): a failed block never has successors running on its state
+    const int *rerun_mask;         // re-issue of a block after a hand-over timeout: only the slots marked here run; null = all
+    int inj_census;                // fault injection (NM_TESTING=1, NM_INJECT_CENSUS): this launch's residency census fails
 };
+
+// status bits reach the host through status[] (last launch) and status_acc[] (everything since the host last looked); a block
+// that stopped (stops) arms the halt word with its launch id
+__device__ __forceinline__ void report_status(const KParams &p, int slot, int bits, bool stops)
+{
+    if (!bits) return;
+    atomicOr(&p.status[slot], bits);
+    if (p.status_acc) atomicOr(&p.status_acc[slot], bits);
+    if (stops && p.halt) atomicCAS(p.halt, 0, (int)p.launch_id);
+}
+// true when an earlier launch stopped on an error the host has not dealt with yet
+__device__ __forceinline__ bool halted(const KParams &p)
+{
+    if (!p.halt) return false;
+    const int h = __hip_atomic_load(p.halt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return h != 0 && h != (int)p.launch_id;
+}
 
 // ------------------------------------------------------------------------------------------ Philox4x32-10
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,

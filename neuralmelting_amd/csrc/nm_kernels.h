@@ -66,11 +66,26 @@ struct LdsArr {
     __device__ __forceinline__ operator T *() const { return ptr(); }
 };
 // the same interface over a pointer into global memory (configurations whose saved copies / lists do not fit in LDS)
+#ifdef NM_PROF
+// Diagnostic build: every index into a global spill / list array is checked against the array's extent; a violation is counted
+// (nm_oob_count, read by nm_prof_oob) and redirected to element 0, so the diagnostic run itself cannot fault.
+__device__ unsigned int nm_oob_count;
+#define NM_BOUND(arr, count) (arr).n = (size_t)(count)
+#define NM_CHECK_INDEX(i, count) ((size_t)(i) < (size_t)(count) ? (size_t)(i) : (atomicAdd(&nm_oob_count, 1u), (size_t)0))
+#else
+#define NM_BOUND(arr, count) do { } while (0)
+#define NM_CHECK_INDEX(i, count) (i)
+#endif
 template <typename T>
 struct GlobArr {
     T *g = nullptr;
-    __device__ __forceinline__ T *ptr() const { return g; }
+#ifdef NM_PROF
+    size_t n = 0;
+    template <typename I> __device__ __forceinline__ T &operator[](I i) const { return g[NM_CHECK_INDEX(i, n)]; }
+#else
     template <typename I> __device__ __forceinline__ T &operator[](I i) const { return g[i]; }
+#endif
+    __device__ __forceinline__ T *ptr() const { return g; }
     __device__ __forceinline__ operator T *() const { return g; }
 };
 template <bool LDS, typename T, size_t OFF> struct ArrSel { using type = LdsArr<T, OFF>; };
@@ -160,7 +175,9 @@ __device__ __attribute__((noinline)) double velocity_create(double t, uint32_t t
     if constexpr (!C::SAVE_LDS) {
         const unsigned long long b = (unsigned long long)(uintptr_t)im_g;
         im.g = (short *)(uintptr_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
-                                    (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b)); // (the builtin returns int)
+                                    (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b)); // (the builtin returns int:
+        // without the uint32_t cast a low word with bit 31 set sign-extends over the high word — a wild pointer)
+        NM_BOUND(im, 3 * C::NMAX);
     }
     N = __builtin_amdgcn_readfirstlane(N); gslot = __builtin_amdgcn_readfirstlane(gslot); parity = __builtin_amdgcn_readfirstlane(parity);
     tag = __builtin_amdgcn_readfirstlane(tag); seed = __builtin_amdgcn_readfirstlane(seed); step = __builtin_amdgcn_readfirstlane(step);
@@ -287,6 +304,7 @@ struct Replica {
     const double *tape = nullptr;
     int tpos = 0, tlen = 0;
     double st_evals = 0.0, st_rebuilds = 0.0, st_eevals = 0.0, st_pairs = 0.0;
+    int st_maxc = 0; // longest list row this thread has built (stats column 8)
     PROF_DECL
 
     __device__ Replica(const KParams &p_, int slot, int q_)
@@ -304,20 +322,25 @@ struct Replica {
             x0.g = a + 6 * (size_t)NMAX; y0.g = a + 7 * (size_t)NMAX; z0.g = a + 8 * (size_t)NMAX;
             im.g = (short *)(a + 9 * (size_t)NMAX);
             wn.g = (signed char *)(im.g + 3 * (size_t)NMAX);
+            NM_BOUND(sx, NMAX); NM_BOUND(sy, NMAX); NM_BOUND(sz, NMAX); NM_BOUND(svx, NMAX); NM_BOUND(svy, NMAX); NM_BOUND(svz, NMAX);
+            NM_BOUND(x0, NMAX); NM_BOUND(y0, NMAX); NM_BOUND(z0, NMAX); NM_BOUND(im, 3 * NMAX); NM_BOUND(wn, 3 * NMAX);
         }
         else if constexpr (!C::SAVEV_LDS) {
             double *a = p.aux_g + ((size_t)slot * p.cus + q_) * C::AUX_DOUBLES;
             svx.g = a; svy.g = a + NMAX; svz.g = a + 2 * (size_t)NMAX;
+            NM_BOUND(svx, NMAX); NM_BOUND(svy, NMAX); NM_BOUND(svz, NMAX);
         }
         if constexpr (!C::SAVEF_LDS) {
             double *a = p.aux_g + ((size_t)slot * p.cus + q_) * C::AUX_DOUBLES + C::AUX_SAVES;
             sfx.g = a; sfy.g = a + NMAX; sfz.g = a + 2 * (size_t)NMAX;
+            NM_BOUND(sfx, NMAX); NM_BOUND(sfy, NMAX); NM_BOUND(sfz, NMAX);
         }
         if constexpr (!C::LIST_LDS) {
             nbr.g = (IdxT *)p.nbr_g + (size_t)slot * 2 * C::NBR_G_ELEMS; // two lists per slot, list_cur = 0
             double *a = p.aux_g + ((size_t)slot * p.cus + q_) * C::AUX_DOUBLES + (C::AUX_DOUBLES - C::AUX_LIST2);
             x0s.g = a; y0s.g = a + NMAX; z0s.g = a + 2 * (size_t)NMAX;
             cnts = (unsigned short *)(a + 3 * (size_t)NMAX);
+            NM_BOUND(x0s, NMAX); NM_BOUND(y0s, NMAX); NM_BOUND(z0s, NMAX); NM_BOUND(nbr, C::NBR_G_ELEMS);
         }
         if (p.tape) { tape = p.tape + p.tape_off[slot]; tlen = p.tape_off[slot + 1] - p.tape_off[slot]; }
     }
@@ -442,7 +465,7 @@ struct Replica {
                 list_cur ^= 1;
                 nbr.g = (IdxT *)p.nbr_g + ((size_t)(gslot - p.slot0) * 2 + list_cur) * C::NBR_G_ELEMS;
                 for (int i = tid; i < N; i += BLOCK) { x0[i] = x0s[i]; y0[i] = y0s[i]; z0[i] = z0s[i]; }
-                for (int i = a0 + tid; i < a1; i += BLOCK) cnt[i] = cnts[i];
+                for (int i = a0 + tid; i < a1; i += BLOCK) cnt[i] = cnts[NM_CHECK_INDEX(i, NMAX)];
                 L0 = L0s;
                 flags |= F_LIST_OK;
             }
@@ -512,7 +535,7 @@ struct Replica {
         if constexpr (C::LIST2) {
             if ((flags & F_LIST_SAVED) && !(flags & F_REBUILT)) { // first rebuild since save(): keep the list the move started from
                 for (int i = tid; i < N; i += BLOCK) { x0s[i] = x0[i]; y0s[i] = y0[i]; z0s[i] = z0[i]; }
-                for (int i = a0 + tid; i < a1; i += BLOCK) cnts[i] = cnt[i];
+                for (int i = a0 + tid; i < a1; i += BLOCK) cnts[NM_CHECK_INDEX(i, NMAX)] = cnt[i];
                 L0s = L0;
                 list_cur ^= 1;
                 nbr.g = (IdxT *)p.nbr_g + ((size_t)(gslot - p.slot0) * 2 + list_cur) * C::NBR_G_ELEMS;
@@ -572,6 +595,7 @@ struct Replica {
                         ++r;
                     }
                 }
+                st_maxc = max(st_maxc, base);
                 if (base > MAXNB) { ovf = 1; base = MAXNB; }
                 if (active && sub == 0) cnt[i] = (unsigned short)base;
             }
@@ -621,13 +645,14 @@ struct Replica {
                             if (c < MAXNB) {
                                 const unsigned int v = (j << 3) << (16 * (c & 1)); // the entry is the byte offset 8 j (pair_vec<.., BYTES>)
                                 if (c & 2) hi |= v; else lo |= v;
-                                if ((c & 3) == 3) { if (active) g[(size_t)(c >> 2) * NMAX + i] = ((unsigned long long)hi << 32) | lo; lo = hi = 0u; }
+                                if ((c & 3) == 3) { if (active) g[NM_CHECK_INDEX((size_t)(c >> 2) * NMAX + i, C::NBR_G_ELEMS / 4)] = ((unsigned long long)hi << 32) | lo; lo = hi = 0u; }
                             }
                             ++c;
                         }
                     }
                 }
-                if (active && c < MAXNB && (c & 3)) g[(size_t)(c >> 2) * NMAX + i] = ((unsigned long long)hi << 32) | lo; // the last, partial chunk
+                if (active && c < MAXNB && (c & 3)) g[NM_CHECK_INDEX((size_t)(c >> 2) * NMAX + i, C::NBR_G_ELEMS / 4)] = ((unsigned long long)hi << 32) | lo; // the last, partial chunk
+                st_maxc = max(st_maxc, c);
                 if (c > MAXNB) { ovf = 1; c = MAXNB; }
                 if (active) cnt[i] = (unsigned short)c;
             }
@@ -808,10 +833,10 @@ struct Replica {
                     const int mych = (nch - sub + TPA - 1) / TPA;         // chunks sub, sub+TPA, ... belong to this thread
                     unsigned long long cur[PF], nxt[PF];
 #pragma unroll
-                    for (int q = 0; q < PF; ++q) cur[q] = q < mych ? nb64[(size_t)(sub + q * TPA) * NMAX + i] : 0ull;
+                    for (int q = 0; q < PF; ++q) cur[q] = q < mych ? nb64[NM_CHECK_INDEX((size_t)(sub + q * TPA) * NMAX + i, C::NBR_G_ELEMS / 4)] : 0ull;
                     for (int k0 = 0; k0 < mych; k0 += PF) {
 #pragma unroll
-                        for (int q = 0; q < PF; ++q) nxt[q] = (k0 + PF + q) < mych ? nb64[(size_t)(sub + (k0 + PF + q) * TPA) * NMAX + i] : 0ull;
+                        for (int q = 0; q < PF; ++q) nxt[q] = (k0 + PF + q) < mych ? nb64[NM_CHECK_INDEX((size_t)(sub + (k0 + PF + q) * TPA) * NMAX + i, C::NBR_G_ELEMS / 4)] : 0ull;
 #pragma unroll
                         for (int q = 0; q < PF; ++q) {
                             if (k0 + q < mych) {
@@ -1704,7 +1729,7 @@ __device__ __forceinline__ bool residency_census(const KParams &p)
     constexpr unsigned int ABORT = 0x80000000u;
     int *flag = (int *)(nm_lds + C::OFF_RED);
     if (threadIdx.x == 0) {
-        const unsigned int want = gridDim.x;
+        const unsigned int want = p.inj_census ? gridDim.x + 1u : gridDim.x; // (injection: a count nobody can complete)
         atomicAdd(p.census, 1u);
         const unsigned long long t0 = wall_clock64();
         int ok = 0;
@@ -1751,6 +1776,7 @@ template <class C>
 __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
 {
     constexpr int BLOCK = C::BLOCK;
+    const unsigned long long t_entry = wall_clock64(); // (stats column 4)
     // cluster mapping: with 8 | nslots the Q members of a cluster share blockIdx % 8, i.e. one XCD (and its L2) under the
     // observed round-robin placement — a speed matter only, the hand-off protocol does not depend on it
     const int Q = p.cus, b = blockIdx.x;
@@ -1763,10 +1789,12 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
     const bool writer = (tid == 0 && qq == 0); // one workgroup of the cluster writes the replica's results
     const int N = p.N;
 
+    if (halted(p)) return; // an earlier block stopped on an error: nothing runs on its state until the host has dealt with it
     if (Q > 1 && p.census && !residency_census<C>(p)) { // nothing has been touched yet
-        if (writer) p.status[slot] |= ST_NOT_RESIDENT;
+        if (writer) report_status(p, slot, ST_NOT_RESIDENT, true);
         return;
     }
+    if (p.rerun_mask && !p.rerun_mask[slot]) return; // re-issue of a block: this replica completed it the first time
     // Which XCD is this workgroup on?  HIP promises no placement; blockIdx % 8 is only the observed round-robin.  The members of a
     // cluster exchange their XCC ids once per block (write-through granules, valid anywhere): sum and sum of squares over the Q
     // members tell every member, identically, whether all ids are equal (Q sum(id^2) == (sum id)^2).
@@ -1793,6 +1821,8 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
     ntp = p.count[6 * slot]; nap = p.count[6 * slot + 1]; ntv = p.count[6 * slot + 2];
     nav = p.count[6 * slot + 3]; nth = p.count[6 * slot + 4]; nah = p.count[6 * slot + 5];
     U0 = 0.0; W0 = 0.0; c_pe = 0.0; c_vol = 0.0; c_volnew = 0.0; c_boxl = 0.0;
+    double &nth_entry = R.ust(22); // (stats column 7)
+    nth_entry = nth;
     const int fatal = ST_BOX_TOO_SMALL | ST_LIST_OVERFLOW | ST_SYNC_TIMEOUT;
 
     // state carried across the evaluation of a move
@@ -1832,8 +1862,8 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
         if (phase == PH_INIT) {
             if (p.eval_only) { // nm_eval: batched lj_energy_force on the resident states
                 if (writer) {
-                    p.evalU[slot] = R.U; p.evalW[slot] = R.W; p.status[slot] |= R.status;
-                    double *st = p.stats + 4 * (size_t)slot;
+                    p.evalU[slot] = R.U; p.evalW[slot] = R.W; report_status(p, slot, R.status, false);
+                    double *st = p.stats + NM_STATS_COLS * (size_t)slot;
                     st[0] += R.st_evals; st[1] += R.st_rebuilds; st[2] += R.st_eevals; st[3] += R.st_pairs;
                 }
                 if (p.evalF) // every workgroup holds the forces of its own atoms
@@ -1992,10 +2022,17 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
     // host reports the reason, and a caller that can cure it (fewer workgroups per replica after a hand-over timeout) may
     // re-issue the block.
     if (R.status & fatal) {
-        if (writer) p.status[slot] |= R.status;
+        if (writer) report_status(p, slot, R.status, true);
         return;
     }
     R.store(buf);
+    { // the longest list row any workgroup of the replica built (stats column 8; positive doubles order like their bit patterns)
+        int mc = R.st_maxc;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mc = max(mc, __shfl_xor(mc, d, 64));
+        if ((tid & 63) == 0 && mc > 0)
+            atomicMax((unsigned long long *)(p.stats + NM_STATS_COLS * (size_t)slot + 8), (unsigned long long)__double_as_longlong((double)mc));
+    }
     if (writer) {
         const double dof = 3.0 * N - 3.0;
         const double temp = smv2 * p.mvv2e / (dof * p.kB);
@@ -2014,9 +2051,10 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
         r[1] = (ntv > 0.0) ? (float)nav / (float)ntv : 0.0f;
         r[2] = (nth > 0.0) ? (float)nah / (float)nth : 0.0f;
         if (R.tape && R.tpos > R.tlen) R.status |= ST_TAPE_EXHAUSTED;
-        p.status[slot] |= R.status;
-        double *st = p.stats + 4 * (size_t)slot;
+        report_status(p, slot, R.status, false);
+        double *st = p.stats + NM_STATS_COLS * (size_t)slot;
         st[0] += R.st_evals; st[1] += R.st_rebuilds; st[2] += R.st_eevals; st[3] += R.st_pairs;
+        st[4] += (double)(wall_clock64() - t_entry); st[5] += R.same_xcd ? 1.0 : 0.0; st[6] += 1.0; st[7] += nth - nth_entry; st[9] = (double)C::MAXNB;
 #ifdef NM_PROF
         if (p.prof) for (int q = 0; q < NM_PROF_SLOTS; ++q) p.prof[(size_t)slot * NM_PROF_SLOTS + q] += R.prof_acc[q];
 #endif
@@ -2024,10 +2062,10 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
 }
 
 // gen_mc_param (remcmc:726-745): one thread per slot
-__global__ void nm_adapt_kernel(int nslots, const int *slot2buf, double *steps, double *count, float *ratio)
+__global__ void nm_adapt_kernel(int nslots, const int *slot2buf, double *steps, double *count, float *ratio, const int *halt)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nslots) return;
+    if (k >= nslots || (halt && *halt)) return; // (a block stopped on an error: its successors wait for the host, nm_api.hip settle)
     const int b = slot2buf[k];
     for (int c = 0; c < 3; ++c) {
         const float a = ratio[3 * k + c];
@@ -2045,10 +2083,10 @@ __global__ void nm_adapt_kernel(int nslots, const int *slot2buf, double *steps, 
 // that is one swap of slot->buffer labels, no coordinate moves.
 __global__ void nm_exchange_kernel(int nrows, int nt, int row0, uint32_t seed, uint32_t step, int *slot2buf,
                                    const double *therm, const double *et, const double *pf, const double *tape,
-                                   double *crit_out, int *nswaps)
+                                   double *crit_out, int *nswaps, const int *halt)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows) return;
+    if (r >= nrows || (halt && *halt)) return;
     const int ppr = nt * (nt - 1) / 2;
     int q = 0, sw = 0;
     for (int vv = nt - 1; vv >= 0; --vv)

@@ -150,6 +150,12 @@ class Engine:
 
     def synchronize(self):
         self._chk(self.lib.nm_synchronize(self.h))
+        self.cus_per_replica = self.lib.nm_cus_per_replica(self.h)  # (a re-issued block may have lowered it)
+
+    def note(self):
+        """what the residency probe gave up at creation and every block that had to be re-issued with fewer workgroups per
+        replica since (nm_create_note); empty when nothing happened"""
+        return self.lib.nm_create_note(self.h).decode()
 
     def status(self):
         """per-slot status bits (include/nm.h NM_ST_*) of the last block; 0 = fine"""
@@ -168,7 +174,8 @@ class Engine:
         return n.value, ms.value
 
     def stats(self, reset=False):
-        """per-slot (evaluations, list rebuilds, energy evaluations, interacting pairs summed over those)"""
+        """per-slot (evaluations, list rebuilds, energy evaluations, interacting pairs summed over those, block time in 100 MHz ticks,
+        blocks handed over inside one XCD, blocks, HMC moves, longest list row built, list slots per atom) since the last reset"""
         s = np.empty((self.nslots, B.NM_STATS_COLS))
         self._chk(self.lib.nm_stats_get(self.h, _dp(s), int(reset)))
         return s

@@ -2,8 +2,12 @@
 
 With whole rows per GPU the sweep is local and runs on the device (nm_exchange).  When a row spans ranks the sweep's
 inputs — (E_tot, V) per slot, 16 bytes each — are all-gathered over RCCL (xGMI), every rank runs the identical sweep with the
-shared Philox stream (global pair index, same draws as nm_exchange_kernel), and the configurations that changed owner are
-all-gathered and re-seated.  All messages are latency-sized."""
+shared Philox stream (global pair index, same draws as nm_exchange_kernel) and so knows the same permutation; only the
+replicas that changed slot then move: inside a rank as a local re-seat, between ranks point to point (one send / receive of
+6 N + 9 doubles per replica: 12 KB at 256 atoms, 98 KB at 2048), never the other replicas' state.  All messages are
+latency-sized."""
+import os
+
 import numpy as np
 
 M0, M1 = 0xD2511F53, 0xCD9E8D57
@@ -62,9 +66,72 @@ def allgather(arr, group_info):
     import torch
     import torch.distributed as dist
     world, use_cuda = group_info
+    if world == 1 and not dist.is_initialized():   # a single process without a group (forced split-row mode in tests)
+        return np.array(arr, dtype=np.float64)
     t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
     if use_cuda:
         t = t.cuda()
     out = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(out, t)
     return np.concatenate([o.cpu().numpy().reshape(1, *arr.shape) for o in out]).reshape(-1, *arr.shape[1:])
+
+
+def transfers(perm, nloc):
+    """what has to move for `perm` when every rank holds `nloc` consecutive slots: a list of (dst_slot, src_slot) for every slot
+    whose content changes, in ascending dst order — the order both ends of every point-to-point message use"""
+    return [(int(k), int(s)) for k, s in enumerate(perm) if int(s) != k]
+
+
+def exchange_split(eng, step, npn, nt, seed, k0, natoms, et, pf, group_info, rank=None):
+    """replica_exchange (remcmc:776-803) for a context that holds a partial pressure row (slots k0 .. k0+eng.nslots of the grid).
+    Returns the number of swaps of the whole sweep.  Entries [0..11] of the state lists travel (remcmc:798): x, v, box, dx dv dt
+    and the thermo scalars — for the replicas that swapped only."""
+    import torch
+    import torch.distributed as dist
+    world, use_cuda = group_info
+    nloc = eng.nslots
+    rows = eng.thermo()
+    ev = allgather(np.stack([rows[:, 1] + rows[:, 2], rows[:, 4]], axis=1), group_info)          # (E_tot, V): 16 B per slot
+    perm, swaps = sweep(npn, nt, seed, step, ev[:, 0], ev[:, 1], et, pf)
+    if not swaps:
+        return swaps
+    moves = transfers(perm, nloc)
+    me = k0 // nloc if rank is None else rank
+    n3 = 3 * natoms
+    width = 2 * n3 + 9
+
+    def pack(slot):  # this rank's slot -> one row
+        x, v, box, d = eng.get_state(slot - k0, 1)
+        return np.concatenate([x[0], v[0], box, d[0], rows[slot - k0, :5]])
+
+    out = {}     # src slot -> packed state (read before anything is overwritten)
+    for dst, src in moves:
+        if src // nloc == me and src not in out:
+            out[src] = pack(src)
+    recv, ops = {}, []
+    for dst, src in moves:                              # ascending dst on every rank: matching order of sends and receives
+        rs, rd = src // nloc, dst // nloc
+        if rs == rd:
+            continue
+        if rs == me:
+            t = torch.from_numpy(out[src])
+            ops.append(dist.P2POp(dist.isend, t.cuda() if use_cuda else t, rd))
+        elif rd == me:
+            t = torch.empty(width, dtype=torch.float64, device='cuda' if use_cuda else 'cpu')
+            recv[dst] = t
+            ops.append(dist.P2POp(dist.irecv, t, rs))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    log = os.environ.get('NM_LOG_EXCHANGE')  # tests: which backend and device the collective used, how many replicas were re-seated
+    if log and me == 0:
+        with open(log, 'a') as f:
+            f.write('%s %s %d\n' % (dist.get_backend() if dist.is_initialized() else 'none', 'cuda' if use_cuda else 'cpu',
+                                    sum(1 for dst, _ in moves if dst // nloc == me)))
+    for dst, src in moves:
+        if dst // nloc != me:
+            continue
+        row = out[src] if src // nloc == me else recv[dst].cpu().numpy()
+        eng.set_state(row[None, :n3], row[None, n3:2 * n3], row[2 * n3:2 * n3 + 1], row[None, 2 * n3 + 1:2 * n3 + 4], k0=dst - k0, nk=1)
+        eng.set_thermo(row[None, 2 * n3 + 4:2 * n3 + 9], k0=dst - k0, nk=1)
+    return swaps

@@ -135,6 +135,9 @@ class Run:
         # contiguous pressure rows per rank: the exchange never leaves a row (remcmc:782-798), so it stays on the device.
         # With fewer rows than ranks the slots are dealt out evenly instead and the sweep runs over RCCL (exchange.py).
         self.split_rows = world > 1 and self.NP < world and self.NS % world == 0
+        if os.environ.get('NM_FORCE_SPLIT_ROWS') == '1' and self.NS % world == 0:
+            self.split_rows = True   # the host-side (collective) exchange also where whole rows would do: lets ONE rank run it
+        self._etpf = None
         if self.split_rows:
             self.nloc = self.NS // world
             self.k0 = rank * self.nloc
@@ -332,22 +335,16 @@ class Run:
             return eng.exchange(count=bool(self.VERBOSE))
         from . import exchange as X
         import torch.distributed as dist
-        info = (self.world, dist.get_backend() == 'nccl')   # gloo (CPU rehearsals, also on a GPU box) gathers host tensors
-        rows = eng.thermo()
-        ev = X.allgather(np.stack([rows[:, 1] + rows[:, 2], rows[:, 4]], axis=1), info)          # (E_tot, V): 16 B per slot
-        et = np.array([init_constant(self.P, self.T, self.EL, *divmod(k, self.NT))[0] for k in range(self.NS)])
-        pf = np.array([init_constant(self.P, self.T, self.EL, *divmod(k, self.NT))[1] for k in range(self.NS)])
-        perm, swaps = X.sweep(self.NP, self.NT, SEED, step, ev[:, 0], ev[:, 1], et, pf)
-        mine = perm[self.k0:self.k0 + self.nloc]
-        if swaps:
-            # entries [0..11] travel (remcmc:798): x, v, box, dx dv dt and the thermo scalars
-            x, v, box, d = eng.get_state()
-            pack = np.concatenate([x, v, box[:, None], d, rows[:, :5]], axis=1)
-            allp = X.allgather(pack, info)[mine]
-            n3 = 3 * self.natoms
-            eng.set_state(allp[:, :n3], allp[:, n3:2 * n3], allp[:, 2 * n3], allp[:, 2 * n3 + 1:2 * n3 + 4])
-            eng.set_thermo(allp[:, 2 * n3 + 4:2 * n3 + 9])
-        return swaps
+        # gloo (CPU rehearsals, also on a GPU box) moves host tensors; a single forced rank has no group of its own
+        if dist.is_initialized():
+            info = (dist.get_world_size(), dist.get_backend() == 'nccl')
+        else:
+            info = (1, False)
+        if self._etpf is None:
+            self._etpf = (np.array([init_constant(self.P, self.T, self.EL, *divmod(k, self.NT))[0] for k in range(self.NS)]),
+                          np.array([init_constant(self.P, self.T, self.EL, *divmod(k, self.NT))[1] for k in range(self.NS)]))
+        return X.exchange_split(eng, step, self.NP, self.NT, SEED, self.k0, self.natoms, self._etpf[0], self._etpf[1], info,
+                                rank=self.rank)
 
     # ------------------------------------------------------------------ main (remcmc:834-1001)
     def main(self):
@@ -438,7 +435,7 @@ def main(argv=None):
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:   # under torch.distributed.run: one rank per GPU over RCCL (also a world of one)
         import torch
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -447,7 +444,12 @@ def main(argv=None):
         # device); the ranks then share the cards round-robin and the few host-side collectives go over gloo.
         backend = os.environ.get('NM_DIST_BACKEND', 'nccl' if use_gpu else 'gloo')
         if use_gpu:
-            local = local % torch.cuda.device_count()
+            ndev = torch.cuda.device_count()
+            if backend == 'gloo':
+                local = local % ndev   # rehearsal: the ranks share the cards round-robin
+            elif local >= ndev:
+                raise SystemExit('rank %d: LOCAL_RANK %d but only %d GPU(s) visible; RCCL needs one device per rank '
+                                 '(NM_DIST_BACKEND=gloo rehearses more ranks than cards)' % (rank, local, ndev))
             torch.cuda.set_device(local)
         dist.init_process_group(backend)
     run = Run(argv, rank=rank, world=world, device=local)
@@ -458,7 +460,7 @@ def run_guarded(run):
     """run.main() of one rank.  An error on one rank of several must not leave the others waiting in a barrier or a collective for
     ever: the failing rank leaves at once with a failure code and the launcher (torch.distributed.run) ends the rest."""
     try:
-        if os.environ.get('NM_TEST_FAIL_RANK') == str(run.rank):   # test hook: tests/test_multiproc.py
+        if os.environ.get('NM_TESTING') == '1' and os.environ.get('NM_TEST_FAIL_RANK') == str(run.rank):   # test hook: tests/test_multiproc.py
             raise RuntimeError('injected failure on rank %d' % run.rank)
         run.main()
     except BaseException:
@@ -468,8 +470,8 @@ def run_guarded(run):
             sys.stderr.flush()
             os._exit(1)
         raise
-    if run.world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 

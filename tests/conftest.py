@@ -3,6 +3,7 @@ import sys
 
 import pytest
 
+os.environ.setdefault('NM_TESTING', '1')  # the library honours its test-only hooks (NM_ASSUME_CUS, NM_INJECT_*) only under this switch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

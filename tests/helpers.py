@@ -110,19 +110,24 @@ class OracleEngine:
 
     def set_state(self, x=None, v=None, box=None, dxdvdt=None, k0=0, nk=None):
         lp = self.loop
-        if x is not None: lp.x = np.array(x, dtype=np.float64).reshape(lp.ns, -1)
-        if v is not None: lp.v = np.array(v, dtype=np.float64).reshape(lp.ns, -1)
+        nk = lp.ns - k0 if nk is None else nk
+        sl = slice(k0, k0 + nk)
+        if x is not None: lp.x[sl] = np.array(x, dtype=np.float64).reshape(nk, -1)
+        if v is not None: lp.v[sl] = np.array(v, dtype=np.float64).reshape(nk, -1)
         if box is not None:
-            lp.box = np.array(box, dtype=np.float64)
-            lp.thermo[:, 4] = lp.box ** 3
-        if dxdvdt is not None: lp.d = np.array(dxdvdt, dtype=np.float64).reshape(lp.ns, 3)
+            lp.box[sl] = np.array(box, dtype=np.float64).reshape(nk)
+            lp.thermo[sl, 4] = lp.box[sl] ** 3
+        if dxdvdt is not None: lp.d[sl] = np.array(dxdvdt, dtype=np.float64).reshape(nk, 3)
 
     def set_thermo(self, th, k0=0, nk=None):
-        self.loop.thermo = np.array(th, dtype=np.float64).reshape(self.loop.ns, 5)
+        nk = self.loop.ns - k0 if nk is None else nk
+        self.loop.thermo[k0:k0 + nk] = np.array(th, dtype=np.float64).reshape(nk, 5)
 
     def get_state(self, k0=0, nk=None, velocities=True):
         lp = self.loop
-        return lp.x.copy(), lp.v.copy(), lp.box.copy(), lp.d.copy()
+        nk = lp.ns - k0 if nk is None else nk
+        sl = slice(k0, k0 + nk)
+        return lp.x[sl].copy(), lp.v[sl].copy(), lp.box[sl].copy(), lp.d[sl].copy()
 
     def set_step(self, step): self.step = int(step)
     def run_block(self, mod): self.loop.run_block(mod, self.step)

@@ -95,6 +95,30 @@ def test_a_failing_rank_ends_the_whole_job(tmp_path, oracle):
 
 
 @pytest.mark.gpu
+def test_split_row_exchange_on_rccl_with_one_rank(tmp_path):
+    """The collective (split-row) exchange on the nccl backend = RCCL.  A one-GPU box cannot hold two RCCL ranks, so the path is
+    forced (NM_FORCE_SPLIT_ROWS=1) in a world of one launched the way the driver launches ranks: the (E_tot, V) all-gather then
+    runs on CUDA tensors over RCCL, the host-side sweep decides, the swapped replicas are re-seated one by one — and the files
+    must equal, byte for byte, those of the same run with the device-side exchange."""
+    argv = '-bm -n sp -e LJ -ss 4 -pn 2 -tn 4 -sn 5 -sm 8 -rd 1 -tr 1.0 1.06'.split()   # narrow range: the sweep does swap
+    one = tmp_path / 'one'; two = tmp_path / 'two'
+    one.mkdir(); two.mkdir()
+    remcmc.Run(argv, cwd=str(one)).main()
+    launch(1, two, argv, script='neuralmelting_amd.remcmc',
+           extra_env={'NM_FORCE_SPLIT_ROWS': '1', 'NM_DIST_BACKEND': 'nccl', 'PYTHONPATH': os.path.dirname(HERE), 'NM_LOG_EXCHANGE': str(two / 'xlog')})
+    for ext in ('.thrm', '.traj'):
+        assert open(str(one / ('sp.lj.fcc.lammps' + ext))).read() == open(str(two / ('sp.lj.fcc.lammps' + ext))).read()
+    ra = np.load(str(one / 'sp.lj.fcc.lammps.rstrt.0004.npy'), allow_pickle=True)
+    rb = np.load(str(two / 'sp.lj.fcc.lammps.rstrt.0004.npy'), allow_pickle=True)
+    for sa, sb in zip(ra, rb):
+        np.testing.assert_array_equal(sa[1], sb[1])
+        np.testing.assert_array_equal(sa[2], sb[2])
+        assert [float(q) for q in sa[3:]] == [float(q) for q in sb[3:]]
+    log = open(str(two / 'xlog')).read().split()
+    assert log[0] == 'nccl' and log[1] == 'cuda' and int(log[2]) > 0     # backend, all-gather on CUDA tensors, replicas re-seated
+
+
+@pytest.mark.gpu
 def test_bench_under_torchrun_uses_rccl(tmp_path):
     """bench.py launched the way the driver launches it (torch.distributed.run, one rank per GPU, backend nccl = RCCL): on this
     one-GPU box that is a world of one, which still exercises the RCCL process group, its barrier and the max/sum all-reduce"""

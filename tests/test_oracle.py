@@ -43,6 +43,33 @@ def test_fcc_known_answer(oracle, sz, pairs, U):
     assert np.abs(s.get_f()).max() < 1e-10
 
 
+# LAMMPS's own shipped benchmark, bench/in.lj (units lj, lattice fcc 0.8442, 20^3 cells = 32000 atoms, pair_style lj/cut 2.5,
+# velocity all create 1.44): the step-0 thermo line of its logs (bench/log.*.lj.*) reads  E_pair -6.7733681  Press -5.0197073.
+# A published third-party value, recalled — no LAMMPS tree exists in this image; re-verify when one is available.  The lattice sum
+# of a perfect fcc crystal does not depend on the supercell once the box exceeds 2 rc, and `velocity create` leaves T_kin = 1.44
+# exactly with dof = 3N - 3, so the pressure is rho 1.44 (1 - 1/32000) + W / 3V whatever supercell evaluates W.  Pins SURVEY.md
+# Appendix C1 (no shift, no tail), C2 (extensive pe) and C5 (pressure = (dof k T + W) / 3V with dof = 3N - 3) by a LAMMPS-produced
+# number rather than by NumPy alone.
+LAMMPS_BENCH_LJ = dict(rho=0.8442, T=1.44, N=32000, e_pair=-6.7733681, press=-5.0197073)
+
+
+def bench_lj_lattice(sz):
+    a = (4.0 / LAMMPS_BENCH_LJ['rho']) ** (1.0 / 3.0)   # 1.67960...
+    return lattice.fcc_fractional(sz) * (sz * a), sz * a
+
+
+@pytest.mark.parametrize('sz', [4, 6])
+def test_lammps_bench_lj_step0(oracle, sz):
+    x, box = bench_lj_lattice(sz)
+    n = len(x)
+    s = oracle.Sim(n)
+    s.set_box(box); s.set_x(x.ravel()); s.set_v(np.zeros(3 * n)); s.setup()
+    B = LAMMPS_BENCH_LJ
+    assert abs(s.pe / n - B['e_pair']) < 5e-8
+    p = B['rho'] * B['T'] * (1.0 - 1.0 / B['N']) + s.virial / (3.0 * box ** 3)
+    assert abs(p - B['press']) < 5e-8
+
+
 def test_relaxed_boxes():
     for P, L in [(0, 6.198413696), (1, 6.170385810), (2, 6.145160290), (4, 6.101094662), (8, 6.030316052)]:
         assert abs(lattice.relax_box(4, P) - L) < 2e-9

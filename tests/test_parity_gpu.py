@@ -64,6 +64,24 @@ def test_eval_known_answer_fcc():
         e.close()
 
 
+@pytest.mark.parametrize('sz', [4, 6])
+def test_eval_lammps_bench_lj_step0(sz):
+    """the step-0 thermo line of LAMMPS's own bench/in.lj logs (E_pair -6.7733681, Press -5.0197073; see tests/test_oracle.py for
+    where the numbers come from and what they pin) through nm_eval"""
+    import neuralmelting_amd as nm
+    from test_oracle import LAMMPS_BENCH_LJ as B, bench_lj_lattice
+    x, box = bench_lj_lattice(sz)
+    n = len(x)
+    P, T = grids(1, 1)
+    e = nm.Engine(n, P, T)
+    e.set_state(x.reshape(1, -1), np.zeros((1, 3 * n)), [box], [[0.03125, 0.03125, 0.00390625]])
+    U, W, f = e.eval()
+    e.close()
+    assert abs(U[0] / n - B['e_pair']) < 5e-8
+    assert abs(B['rho'] * B['T'] * (1.0 - 1.0 / B['N']) + W[0] / (3.0 * box ** 3) - B['press']) < 5e-8
+    assert np.abs(f).max() < 1e-9
+
+
 @pytest.mark.parametrize('bulk', [True, False])
 def test_block_trace_parity(oracle, bulk):
     """one block of moves, move by move: branch, decision, criterion, energy after (a-2..a-7)"""

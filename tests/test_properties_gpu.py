@@ -127,7 +127,7 @@ def test_list_overflow_is_reported_by_the_whole_cluster_without_timeouts(np_rows
 def test_grid_that_cannot_be_resident_falls_back_to_fewer_workgroups_per_replica(monkeypatch):
     """Cluster launch safety.  NM_ASSUME_CUS makes nm_create believe the chip has 512 CUs, so it first tries 8 workgroups per
     replica for 64 replicas = 512 workgroups of 82 KB LDS each, twice what the chip can hold at once.  The residency probe
-    (a census launch) must see that the grid does not gather, fall back to 4 per replica, say so in nm_last_error, and the
+    (a census launch) must see that the grid does not gather, fall back to 4 per replica, say so in nm_create_note, and the
     chains must then be the ones a plain 4-per-replica context produces — no 2 s hand-over timeouts, no hang."""
     import time
     import neuralmelting_amd as nm
@@ -142,7 +142,8 @@ def test_grid_that_cannot_be_resident_falls_back_to_fewer_workgroups_per_replica
             monkeypatch.delenv('NM_ASSUME_CUS')
         t0 = time.perf_counter()
         e = nm.Engine(256, P, T)
-        note = e.lib.nm_last_error(e.h).decode()
+        note = e.note()
+        assert e.lib.nm_last_error(e.h).decode() == ''  # a note is not an error
         assert e.cus_per_replica == 4
         if assume:
             assert '8 workgroups per replica (512 in all) did not gather' in note
@@ -180,13 +181,116 @@ def test_a_block_that_ends_on_an_error_leaves_the_state_as_it_was(monkeypatch):
     assert 8 <= stopped.sum() < 64 and (st[stopped] == 1).all()            # NM_ST_LIST_OVERFLOW; the cold slots rebuild too rarely to be hit
     xo, vo, bo = np.empty((64, 768)), np.empty((64, 768)), np.empty(64)
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
-    rc = e.lib.nm_get_state(e.h, 0, 64, dp(xo), dp(vo), dp(bo), None)     # the copy succeeds; the return code repeats the error
-    assert rc == -3
+    rc = e.lib.nm_get_state(e.h, 0, 64, dp(xo), dp(vo), dp(bo), None)     # the error was reported once; the context stays usable
+    assert rc == 0
     np.testing.assert_array_equal(xo[stopped], x1[stopped])
     np.testing.assert_array_equal(vo[stopped], v1[stopped])
     np.testing.assert_array_equal(bo[stopped], box1[stopped])
     assert (np.abs(xo[~stopped] - x1[~stopped]).max(1) > 0).all()          # the others completed their 48 moves
+    # the caller re-issues (the injection is off now): the block runs, nm_get_status is that of the LAST block, nothing is sticky
+    e.set_step(2)
+    e.run_block(8)
+    e.synchronize()
+    assert (e.status() == 0).all()
+    rows = e.thermo()
+    assert np.isfinite(rows).all() and (rows[:, 8] + rows[:, 10] + rows[:, 12] == 8).all()
     e.close()
+
+
+def test_nothing_runs_behind_a_block_that_stopped(monkeypatch):
+    """a block stops on an error (injected overflow) with adapt, exchange and two more cycles already queued behind it: none of
+    them may run on the stale state — the step sizes, the slot->buffer map and the configurations of ALL slots are those of the
+    failed block's start for the slots that stopped, and exactly one block old for the others"""
+    import neuralmelting_amd as nm
+    from neuralmelting_amd import lattice
+    P, T = grids(8, 8)
+    x, v, box, d = lattice.init_states(4, P, T, 0.03125, 0.03125)
+    e = nm.Engine(256, P, T)
+    e.set_state(x, v, box, d)
+    e.run_block(8)
+    e.adapt()
+    e.exchange(count=False)
+    e.synchronize()
+    x1, v1, box1, d1 = e.get_state()
+    perm1 = e.perm()
+    monkeypatch.setenv('NM_INJECT_OVERFLOW', '3,1')
+    for step in (1, 2, 3):
+        e.set_step(step)
+        e.run_block(48)
+        e.adapt()
+        e.exchange(count=False)
+    with pytest.raises(nm.NMError):
+        e.synchronize()
+    monkeypatch.delenv('NM_INJECT_OVERFLOW')
+    stopped = e.status() != 0
+    assert stopped.any() and not stopped.all()
+    x2, v2, box2, d2 = e.get_state()
+    np.testing.assert_array_equal(e.perm(), perm1)             # no exchange ran
+    np.testing.assert_array_equal(d2, d1)                      # no adapt ran
+    np.testing.assert_array_equal(x2[stopped], x1[stopped])
+    # the replicas that completed the failed block ran it ONCE (48 moves), not three times: same as a clean context does
+    f = nm.Engine(256, P, T)
+    f.set_state(x1, v1, box1, d1)
+    f.set_step(1)
+    f.run_block(48)
+    x3 = f.get_state()[0]
+    f.close()
+    np.testing.assert_array_equal(x2[~stopped], x3[~stopped])
+    e.close()
+
+
+def test_a_launch_that_is_not_resident_is_reissued_with_fewer_workgroups(monkeypatch):
+    """Self-healing cluster launches.  The residency census of the context's second cluster launch is made to fail
+    (NM_INJECT_CENSUS=1: what a CU mask or another process taking CUs between nm_create and the launch does) with the next
+    two cycles already queued behind it.  Nothing has been touched and nothing behind it runs; the next host call re-creates the
+    launch at 2 workgroups per replica, re-issues the block and everything behind it, says so in nm_create_note — and the
+    chains are bit for bit those of a context that ran the first cycle at 4 per replica and the rest at 2."""
+    import neuralmelting_amd as nm
+    from neuralmelting_amd import lattice
+    P, T = grids(8, 8)
+    x, v, box, d = lattice.init_states(4, P, T, 0.03125, 0.03125)
+    mod = 12
+
+    def cycle(e, step):
+        e.set_step(step)
+        e.run_block(mod)
+        e.adapt()
+        e.exchange(count=False)
+
+    monkeypatch.setenv('NM_INJECT_CENSUS', '1')
+    a = nm.Engine(256, P, T)
+    assert a.cus_per_replica == 4 and a.note() == ''
+    a.set_state(x, v, box, d)
+    for step in range(3):
+        cycle(a, step)
+    a.synchronize()                                            # notices, re-issues cycles 1 and 2 at Q = 2
+    monkeypatch.delenv('NM_INJECT_CENSUS')
+    assert a.cus_per_replica == 2
+    assert 'step 1 stopped at 4 workgroups per replica (grid not resident); re-issued at 2' in a.note()
+    assert a.lib.nm_last_error(a.h).decode() == ''
+    assert (a.status() == 0).all()
+    ra, (xa, va, ba, da) = a.thermo(), a.get_state()
+    a.close()
+
+    b = nm.Engine(256, P, T)                                   # cycle 0 at 4 workgroups per replica
+    b.set_state(x, v, box, d)
+    cycle(b, 0)
+    rb, (xb, vb, bb, db) = b.thermo(), b.get_state()
+    b.close()
+    monkeypatch.setenv('NM_CUS_PER_REPLICA', '2')
+    c = nm.Engine(256, P, T)                                   # cycles 1, 2 at 2
+    assert c.cus_per_replica == 2
+    c.set_state(xb, vb, bb, db)
+    c.set_thermo(rb[:, :5])
+    cycle(c, 1)
+    cycle(c, 2)
+    rc_, (xc, vc, bc, dc) = c.thermo(), c.get_state()
+    c.close()
+    np.testing.assert_array_equal(xa, xc)
+    np.testing.assert_array_equal(va, vc)
+    np.testing.assert_array_equal(ba, bc)
+    np.testing.assert_array_equal(da, dc)
+    np.testing.assert_array_equal(ra[:, :8], rc_[:, :8])
 
 
 def test_box_smaller_than_twice_the_cutoff_is_refused():

@@ -83,3 +83,29 @@ def test_share_replays_bit_for_bit(name, el, sz, nrows, np_all, nt, q, mod, slot
     steps = a['rows'][:, :, 5:8]
     f = steps[1] / steps[0]
     assert np.isin(np.round(f, 6), [0.9375, 1.0, 1.0625]).all()
+
+
+def test_equilibrated_8cubed_lists_keep_clear_of_their_slots():
+    """The 2048-atom kernel keeps 224 list slots per atom (lists in HBM; skin 0.6 => list radius 3.1).  The densest states of the
+    BASELINE grids are those of the highest pressure row, P* = 8: its 32 temperatures — cold crystal to hot dense liquid — run
+    for 30 cycles (adaptation, exchange: equilibrated chains, HMC accepting), and the longest row any rebuild produced must stay
+    well below the slots there are (nm_stats_get columns 8, 9).  An overflow would stop the run (NM_ST_LIST_OVERFLOW)."""
+    import neuralmelting_amd as nm
+    P = np.linspace(1.0, 8.0, 32, dtype=np.float32)
+    T = np.linspace(0.25, 2.5, 32, dtype=np.float32)
+    x, v, box, d = lattice.init_states(8, P, T, 0.03125, 0.03125, row0=31, nrows=1)
+    e = nm.Engine(2048, P, T, row0=31, nrows=1)
+    e.set_state(x, v, box, d)
+    for step in range(30):
+        e.set_step(step)
+        e.run_block(64)
+        e.adapt()
+        e.exchange(count=False)
+    e.synchronize()
+    st = e.stats()
+    rows = e.thermo()
+    e.close()
+    slots = st[0, 9]
+    assert slots == 224
+    assert st[:, 1].sum() > 30 * 32                      # the lists were rebuilt many times
+    assert 130 <= st[:, 8].max() <= 0.85 * slots, st[:, 8].max()
