@@ -200,8 +200,11 @@ def main():
     if args.equil > 0:
         acc = None
         while step < args.equil or acc is None or not (0.4 <= acc <= 0.6):
-            if step >= args.equil + 40:
-                break                      # (adaptation oscillates around 0.5; do not wait for ever)
+            # adaptation oscillates around 0.5: do not wait for ever.  The reference's iterative position move never undoes a rejected
+            # trial while its step size keeps growing (remcmc:522-545, 733-737): after some tens of cycles atoms overlap and energies
+            # leave the floating-point range, as they would in the reference; that mode is timed at cycle `equil`, no later
+            if step >= args.equil + (0 if args.iterative else 40):
+                break
             acc = hmc_acceptance(step)
             step += 1
             equil += 1

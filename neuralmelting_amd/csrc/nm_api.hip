@@ -27,14 +27,15 @@ namespace {
 #define NM_SMALL_TPA 2
 #endif
 // cluster variants of the small kernel: Q workgroups per replica, threads-per-atom scaled so that all 512 threads work
-typedef Cfg<NM_SMALL_BLOCK, 2 * NM_SMALL_TPA, 256, 192, unsigned char, true, true> CfgSmallQ2;
-typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 192, unsigned char, true, true> CfgSmallQ4;
-typedef Cfg<NM_SMALL_BLOCK, 8 * NM_SMALL_TPA, 256, 256, unsigned char, true, true> CfgSmallQ8; // grids of <= 32 replicas
-typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 192, unsigned char, true, true> CfgSmall;     // N <= 256: everything incl. the byte list in LDS
+// (a cluster stores the list rows of its own atoms only, and keeps the list twice: a rejected move goes back to the one it started from)
+typedef Cfg<NM_SMALL_BLOCK, 2 * NM_SMALL_TPA, 256, 192, unsigned char, true, true, 0, 128, true, true> CfgSmallQ2;
+typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 192, unsigned char, true, true, 0, 64, true, true> CfgSmallQ4;
+typedef Cfg<NM_SMALL_BLOCK, 8 * NM_SMALL_TPA, 256, 256, unsigned char, true, true, 0, 32, true, true> CfgSmallQ8; // grids of <= 32 replicas
+typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 192, unsigned char, true, true, 0, 256, true, true> CfgSmall;     // N <= 256: everything incl. the byte lists in LDS
 // element Al: Sutton-Chen EAM, 4^3 cells only (BASELINE config 4); 200 neighbour slots (134 within rc+skin in the crystal)
 typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 256, unsigned char, true, true, 1> CfgSmallSC;
-typedef Cfg<NM_SMALL_BLOCK, 2 * NM_SMALL_TPA, 256, 256, unsigned char, true, true, 1> CfgSmallSCQ2;
-typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 256, unsigned char, true, true, 1> CfgSmallSCQ4;
+typedef Cfg<NM_SMALL_BLOCK, 2 * NM_SMALL_TPA, 256, 256, unsigned char, true, true, 1, 128, true, true> CfgSmallSCQ2; // (own rows, two lists)
+typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 256, unsigned char, true, true, 1, 64, true, true> CfgSmallSCQ4;
 typedef Cfg<512, 1, 864, 160, unsigned short, false, true> CfgMid;     // N <= 864: list in HBM/L2, saved copies in LDS (also at 2 workgroups per replica)
 // cluster variants: own atoms 216 / 108
 typedef Cfg<512, 2, 864, 160, unsigned short, false, true> CfgMidQ4;
@@ -589,12 +590,14 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     // dynamic LDS above 64 KiB has to be requested per kernel
     if (c->kind == 0) {
         CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmall::LDS_BYTES));
-        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallQ2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmall::LDS_BYTES));
-        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallQ4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmall::LDS_BYTES));
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallQ2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmallQ2::LDS_BYTES));
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallQ4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmallQ4::LDS_BYTES));
+        static_assert(CfgSmall::LDS_BYTES <= 160 * 1024 && CfgSmallQ2::LDS_BYTES <= 160 * 1024, "two byte lists per workgroup must fit the CU's LDS");
         CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallQ8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmallQ8::LDS_BYTES));
         CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallSC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmallSC::LDS_BYTES));
-        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallSCQ2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmallSC::LDS_BYTES));
-        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallSCQ4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmallSC::LDS_BYTES));
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallSCQ2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmallSCQ2::LDS_BYTES));
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgSmallSCQ4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgSmallSCQ4::LDS_BYTES));
+        static_assert(CfgSmallSCQ2::LDS_BYTES <= 160 * 1024 && CfgSmallSC::LDS_BYTES <= 160 * 1024, "");
     }
     else if (c->kind == 1) {
         CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgMid>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgMid::LDS_BYTES));
@@ -925,6 +928,17 @@ int nm_prof_oob(nm_ctx *c, unsigned int *count)
     HIPCHK(c, hipMemcpyFromSymbol(count, HIP_SYMBOL(nm::nm_oob_count), sizeof(unsigned int)));
     const unsigned int zero = 0;
     HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(nm::nm_oob_count), &zero, sizeof(unsigned int)));
+    return NM_OK;
+}
+// diagnostic build only: rows of freshly built neighbour lists that lacked an atom inside rc + skin (exact fp64 check after every
+// rebuild, Replica::rebuild) since the last call
+int nm_prof_list_miss(nm_ctx *c, unsigned int *count)
+{
+    if (!c || !count) return NM_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyFromSymbol(count, HIP_SYMBOL(nm::nm_list_miss), sizeof(unsigned int)));
+    const unsigned int zero = 0;
+    HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(nm::nm_list_miss), &zero, sizeof(unsigned int)));
     return NM_OK;
 }
 // diagnostic build only: cycle sums per section and slot, [nslots][16]

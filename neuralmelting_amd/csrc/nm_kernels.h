@@ -70,6 +70,7 @@ struct LdsArr {
 // Diagnostic build: every index into a global spill / list array is checked against the array's extent; a violation is counted
 // (nm_oob_count, read by nm_prof_oob) and redirected to element 0, so the diagnostic run itself cannot fault.
 __device__ unsigned int nm_oob_count;
+__device__ unsigned int nm_list_miss; // rows of a freshly built list that lack an atom inside rc + skin (Replica::rebuild's self-check)
 #define NM_BOUND(arr, count) (arr).n = (size_t)(count)
 #define NM_CHECK_INDEX(i, count) ((size_t)(i) < (size_t)(count) ? (size_t)(i) : (atomicAdd(&nm_oob_count, 1u), (size_t)0))
 #else
@@ -95,8 +96,13 @@ template <typename T, size_t OFF> struct ArrSel<false, T, OFF> { using type = Gl
 // constant offset: no address registers are needed for them (with run-time strides the eighteen array bases were
 // spilled to scratch and reloaded inside the pair loop).
 template <int BLOCK_, int TPA_, int NMAX_, int MAXNB_, typename IdxT_, bool LIST_LDS_, bool SAVE_LDS_, int POT_ = 0, int NLIST_ = NMAX_,
-          bool SAVEV_LDS_ = SAVE_LDS_>
+          bool SAVEV_LDS_ = SAVE_LDS_, bool LDS_LIST2_ = false>
 struct Cfg {
+    // LDS_LIST2: an LDS list is kept twice as well (see LIST2 below): the second copy, the reference positions and the row lengths
+    // that belong to the list a move started from live in LDS too.  Affordable once a cluster configuration stores only the rows
+    // of its own atoms (NLIST = NMAX / Q).
+    static constexpr bool LDS_LIST2 = LDS_LIST2_;
+    static_assert(!LDS_LIST2_ || (LIST_LDS_ && SAVE_LDS_), "a second LDS list needs the first one and the saved copies in LDS");
     // NLIST: rows of an LDS list.  A workgroup only builds and reads the rows of its own atoms; a cluster configuration whose own
     // range is a fixed fraction of NMAX stores just those (row = i - a0).  SAVEV_LDS: the saved velocities (touched twice per
     // HMC move) may live in the global spill while the saved positions and the list reference stay in LDS — together these two
@@ -127,15 +133,22 @@ struct Cfg {
     static constexpr size_t OFF_IMG = OFF_CNT + pad8((size_t)NMAX * sizeof(unsigned short));
     static constexpr size_t OFF_WN = OFF_IMG + pad8((size_t)3 * NMAX * sizeof(short));
     static constexpr size_t OFF_NBR = SAVE_LDS ? OFF_WN + pad8((size_t)3 * NMAX) : OFF_IMG;
-    static constexpr size_t OFF_RHO = LIST_LDS ? OFF_NBR + pad8((size_t)MAXNB * NLIST * sizeof(IdxT)) : OFF_NBR; // EAM densities
-    static constexpr size_t LDS_BYTES = OFF_RHO + (POT ? (size_t)NMAX * sizeof(double) : 0);
+    static constexpr size_t LIST_BYTES = LIST_LDS ? pad8((size_t)MAXNB * NLIST * sizeof(IdxT)) : 0; // one LDS list
+    static constexpr size_t OFF_RHO = OFF_NBR + (LDS_LIST2 ? 2 : 1) * LIST_BYTES; // EAM densities
+    static constexpr size_t OFF_X0S = OFF_RHO + (POT ? (size_t)NMAX * sizeof(double) : 0); // LDS_LIST2: reference positions of the saved list
+    static constexpr size_t OFF_CNTS = OFF_X0S + (LDS_LIST2 ? A3 : 0);                     //            and its row lengths
+    static constexpr size_t LDS_NATURAL = OFF_CNTS + (LDS_LIST2 ? pad8((size_t)NMAX * sizeof(unsigned short)) : 0);
+    // One workgroup per CU, by construction: a cluster's census and the Q selection count on it (nm_probe_kernel asserts it), and
+    // two workgroups of different replicas on one CU measured slower.  A configuration that would fit twice
+    // into the CU's 160 KB asks for a little more than half of them.
+    static constexpr size_t LDS_BYTES = LDS_NATURAL > (size_t)82 * 1024 ? LDS_NATURAL : (size_t)82 * 1024;
     // per-slot global spill when the saved copies do not fit in LDS: sav, savv, x0 (9 NMAX doubles) + images + wrap counts
     static constexpr size_t AUX_SAVES = SAVE_LDS ? (SAVEV_LDS ? 0 : (size_t)3 * NMAX) : (size_t)9 * NMAX + ((size_t)3 * NMAX * 3 + 7) / 8;
     // lists outside LDS are kept TWICE per slot (LIST2): a trial that rebuilt and is then rejected goes back to the list it started
     // from instead of rebuilding again (Replica::save / rebuild / restore); with it the reference positions and the row lengths
     // of that list (3 NMAX doubles + NMAX 16-bit counts per workgroup)
-    static constexpr bool LIST2 = !LIST_LDS_;
-    static constexpr size_t AUX_LIST2 = LIST2 ? (size_t)3 * NMAX + ((size_t)NMAX + 3) / 4 : 0;
+    static constexpr bool LIST2 = !LIST_LDS_ || LDS_LIST2_;
+    static constexpr size_t AUX_LIST2 = !LIST_LDS_ ? (size_t)3 * NMAX + ((size_t)NMAX + 3) / 4 : 0;
     static constexpr size_t AUX_DOUBLES = AUX_SAVES + (SAVEF_LDS ? 0 : (size_t)3 * NMAX) + AUX_LIST2; // ... + the saved forces + LIST2
     static constexpr size_t NBR_G_ELEMS = LIST_LDS ? 0 : (size_t)MAXNB * NMAX; // per-slot global list
     // Lists that live in HBM/L2 are stored in chunks of CH consecutive neighbours of one atom ([chunk][atom][CH]) so that one
@@ -296,10 +309,17 @@ struct Replica {
     __device__ __forceinline__ void set_fresh(bool b) { flags = b ? (flags | F_FRESH) : (flags & ~F_FRESH); }
     int status = 0;
     // LIST2: the other list of the slot, and what belongs to the list a move started from
-    GlobArr<double> x0s, y0s, z0s;
-    unsigned short *cnts = nullptr;
+    typename ArrSel<C::LDS_LIST2, double, C::OFF_X0S>::type x0s; typename ArrSel<C::LDS_LIST2, double, C::OFF_X0S + A1>::type y0s;
+    typename ArrSel<C::LDS_LIST2, double, C::OFF_X0S + 2 * A1>::type z0s;
+    typename ArrSel<C::LDS_LIST2, unsigned short, C::OFF_CNTS>::type cnts;
     double L0s = 0.0;
     int list_cur = 0;
+    // the list in force: LDS lists kept twice sit one behind the other
+    __device__ __forceinline__ IdxT *nbr_cur() const
+    {
+        if constexpr (C::LDS_LIST2) return (IdxT *)(nm_lds + C::OFF_NBR + (size_t)list_cur * C::LIST_BYTES);
+        else return nbr.ptr();
+    }
     bool same_xcd = false; // all workgroups of the cluster run on one XCD (read from the hardware, not assumed from blockIdx)
     const double *tape = nullptr;
     int tpos = 0, tlen = 0;
@@ -339,8 +359,8 @@ struct Replica {
             nbr.g = (IdxT *)p.nbr_g + (size_t)slot * 2 * C::NBR_G_ELEMS; // two lists per slot, list_cur = 0
             double *a = p.aux_g + ((size_t)slot * p.cus + q_) * C::AUX_DOUBLES + (C::AUX_DOUBLES - C::AUX_LIST2);
             x0s.g = a; y0s.g = a + NMAX; z0s.g = a + 2 * (size_t)NMAX;
-            cnts = (unsigned short *)(a + 3 * (size_t)NMAX);
-            NM_BOUND(x0s, NMAX); NM_BOUND(y0s, NMAX); NM_BOUND(z0s, NMAX); NM_BOUND(nbr, C::NBR_G_ELEMS);
+            cnts.g = (unsigned short *)(a + 3 * (size_t)NMAX);
+            NM_BOUND(x0s, NMAX); NM_BOUND(y0s, NMAX); NM_BOUND(z0s, NMAX); NM_BOUND(cnts, NMAX); NM_BOUND(nbr, C::NBR_G_ELEMS);
         }
         if (p.tape) { tape = p.tape + p.tape_off[slot]; tlen = p.tape_off[slot + 1] - p.tape_off[slot]; }
     }
@@ -463,9 +483,9 @@ struct Replica {
             // next evaluation like that of any list.
             if ((flags & F_LIST_SAVED) && (flags & F_REBUILT)) {
                 list_cur ^= 1;
-                nbr.g = (IdxT *)p.nbr_g + ((size_t)(gslot - p.slot0) * 2 + list_cur) * C::NBR_G_ELEMS;
+                if constexpr (!C::LIST_LDS) nbr.g = (IdxT *)p.nbr_g + ((size_t)(gslot - p.slot0) * 2 + list_cur) * C::NBR_G_ELEMS;
                 for (int i = tid; i < N; i += BLOCK) { x0[i] = x0s[i]; y0[i] = y0s[i]; z0[i] = z0s[i]; }
-                for (int i = a0 + tid; i < a1; i += BLOCK) cnt[i] = cnts[NM_CHECK_INDEX(i, NMAX)];
+                for (int i = a0 + tid; i < a1; i += BLOCK) cnt[i] = cnts[i];
                 L0 = L0s;
                 flags |= F_LIST_OK;
             }
@@ -501,51 +521,71 @@ struct Replica {
         else return ((size_t)(r / C::CH) * NMAX + i) * C::CH + (r % C::CH);
     }
 
+    // One candidate test of the list rebuild on 16-bit fixed-point coordinates (units of L / 65536): xy holds x | y << 16, z the
+    // third coordinate.  v_pk_sub_i16 wraps modulo 2^16, which IS the minimum image; two v_dot2 give the squared separation (at most
+    // 3 x 2^30: no wrap as an unsigned 32-bit number); the compare's carry is shifted into the mask by v_addc (m + m + carry), so a
+    // test is six VALU instructions.  The result of the b-th test of a run of 32 ends up in bit 31 - b (the callers reverse).
+    typedef short v2s16 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ unsigned int test16(unsigned int m, unsigned int xyi, unsigned int zi, unsigned int xyj, unsigned int zj,
+                                                          unsigned int t2)
+    {
+        const v2s16 d0 = __builtin_bit_cast(v2s16, xyi) - __builtin_bit_cast(v2s16, xyj);
+        const v2s16 d1 = __builtin_bit_cast(v2s16, zi) - __builtin_bit_cast(v2s16, zj);
+        int r = __builtin_amdgcn_sdot2(d0, d0, 0, false);
+        r = __builtin_amdgcn_sdot2(d1, d1, r, false);
+        asm("v_cmp_gt_u32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(r), "v"(t2) : "vcc");
+        return m;
+    }
+
     // Verlet-list rebuild.
-    // * The candidate test runs in fp32 on a float copy of the positions: VALU issue bounds the build and fp32 issues at twice the
-    //   fp64 rate.  The copy lives in the force array, which is dead here: every caller of rebuild() is about to run the pair loop
-    //   that rewrites it.  The radius is enlarged by the worst-case fp32 error (positions rounded to 2^-24 relative of at most
-    //   1.5 L, difference, image shift, square: < 16 L 2^-24 in r), so the list is a superset of the exact one: the extra entries lie
-    //   beyond rc + skin and are masked by the pair loop's exact fp64 cutoff test, contributing an exact zero in the same place
-    //   of the sum.  (The list itself is not observable in any result.)  The copy is in units of the box edge, s = x / L, so that
-    //   the minimum image of a separation is fract(s_i - s_j + 1/2) - 1/2: with s_i + 1/2 held per row that is a subtraction,
-    //   v_fract_f32 and another subtraction per component instead of subtraction, multiplication, v_rndne and an fma (errors:
-    //   2^-24 of |s| <= 1.5, of s_i + 1/2 <= 2.5 and of their difference <= 3, fract and the last step exact: 7 x 2^-24 per
-    //   component, 12.2 L 2^-24 in r, inside the 16 L 2^-24 allowed for).
+    // * The candidate test runs on a 16-bit fixed-point copy of the positions, u = round(65536 x / L) mod 2^16 per coordinate (round 3;
+    //   fp32 in round 2, fp64 in round 1): VALU issue bounds the build, and in this form a test is six instructions (test16) against
+    //   fourteen to eighteen in fp32.  The copy lives in the force array, which is dead here: every caller of rebuild() is about to
+    //   run the pair loop that rewrites it.  Each coordinate is off by at most half a unit, each component of a separation by one,
+    //   the separation itself by at most sqrt(3) units: the test radius is rc + skin + 1.8 units (1.7e-4 at L = 6.1, 3.4e-4 at
+    //   L = 12.2), so the list is a superset of the exact one: the extra entries lie beyond rc + skin and are masked by the pair
+    //   loop's exact fp64 cutoff test, contributing an exact zero in the same place of the sum.  (The list itself is not observable
+    //   in any result.)  tests/test_list_fixed_point.py restates the arithmetic in numpy and checks the superset property.
     // * Lists in LDS (N <= 256, and the 6^3 system at 8 workgroups per replica): TPA threads per row (see below).
     // * Lists in HBM/L2 (one thread per atom in the pair loop): one THREAD per row.  All lanes of a wave test the same candidate
-    //   j at the same time, so its coordinates are three broadcast LDS reads, there is no cross-lane step at all, and the loop over
-    //   j unrolls into independent tests; a thread packs four indices into the 8-byte chunk the pair loop reads and stores it
-    //   whole (lanes = consecutive atoms = consecutive words of the [chunk][atom] layout).  The wave-per-row form took ~0.45 ms per
+    //   j at the same time: each lane fetches one of 64 candidates (a coalesced read) and the block is walked with v_readlane, so a
+    //   candidate reaches all lanes as two scalar operands, there is no cross-lane step at all, and the loop over j unrolls into
+    //   independent tests; a thread packs four indices into the 8-byte chunk the pair loop reads and stores it whole (lanes =
+    //   consecutive atoms = consecutive words of the [chunk][atom] layout).  The wave-per-row form of round 1 took ~0.45 ms per
     //   rebuild of a 2048-atom replica — bound by its dependent chain index read -> gathers -> ballot, 32 times per row — which
     //   was ~70 % of the 8^3 kernel once the chains have equilibrated (one to two rebuilds per move when HMC accepts); a (y, z)
     //   column binning with a 5 x 5 stencil in front of it gained only 1.3x and is gone again.
     __device__ void rebuild()
     {
         [[maybe_unused]] const int lane = tid & 63;
-        constexpr int FSTRIDE = C::LIST_LDS ? NMAX + NMAX / 32 + 1 : NMAX; // LDS lists: skewed copy, element j at j + j / 32
-        float *xf = (float *)(nm_lds + C::OFF_FRC), *yf = xf + FSTRIDE, *zf = yf + FSTRIDE;
-        static_assert((size_t)3 * FSTRIDE * sizeof(float) <= (size_t)3 * NMAX * sizeof(double), "");
-        const double invLd = 1.0 / L;
+        // one 8-byte word per atom: {x | y << 16, z}; LDS lists: skewed copy, element j at j + j / 32
+        unsigned long long *cf = (unsigned long long *)(nm_lds + C::OFF_FRC);
+        static_assert((size_t)(NMAX + NMAX / 32 + 64 + 2) * sizeof(unsigned long long) <= (size_t)3 * NMAX * sizeof(double), "");
+        const double sc16 = 65536.0 / L, invLd = 1.0 / L;
         for (int i = tid; i < N; i += BLOCK) {
             const int is = C::LIST_LDS ? i + (i >> 5) : i;
-            xf[is] = (float)(px[i] * invLd); yf[is] = (float)(py[i] * invLd); zf[is] = (float)(pz[i] * invLd);
+            // (v_fract_f64 first: a trajectory that is about to be rejected for an astronomic energy — the reference's never-undone
+            //  iterative trials produce overlapping atoms — may carry coordinates far beyond the integer range)
+            const unsigned int ux = (unsigned int)__double2int_rn(__builtin_amdgcn_fract(px[i] * invLd) * 65536.0) & 0xFFFFu,
+                               uy = (unsigned int)__double2int_rn(__builtin_amdgcn_fract(py[i] * invLd) * 65536.0) & 0xFFFFu,
+                               uz = (unsigned int)__double2int_rn(__builtin_amdgcn_fract(pz[i] * invLd) * 65536.0) & 0xFFFFu;
+            cf[is] = (unsigned long long)(ux | (uy << 16)) | ((unsigned long long)uz << 32);
         }
         set_fresh(false); // the forces are gone
         if constexpr (C::LIST2) {
             if ((flags & F_LIST_SAVED) && !(flags & F_REBUILT)) { // first rebuild since save(): keep the list the move started from
                 for (int i = tid; i < N; i += BLOCK) { x0s[i] = x0[i]; y0s[i] = y0[i]; z0s[i] = z0[i]; }
-                for (int i = a0 + tid; i < a1; i += BLOCK) cnts[NM_CHECK_INDEX(i, NMAX)] = cnt[i];
+                for (int i = a0 + tid; i < a1; i += BLOCK) cnts[i] = cnt[i];
                 L0s = L0;
                 list_cur ^= 1;
-                nbr.g = (IdxT *)p.nbr_g + ((size_t)(gslot - p.slot0) * 2 + list_cur) * C::NBR_G_ELEMS;
+                if constexpr (!C::LIST_LDS) nbr.g = (IdxT *)p.nbr_g + ((size_t)(gslot - p.slot0) * 2 + list_cur) * C::NBR_G_ELEMS;
                 flags |= F_REBUILT;
             }
         }
-        const double rl = p.rc + p.skin + 16.0 * L * 5.9604644775390625e-8;
-        const float rl2 = (float)(rl * rl * invLd * invLd * (1.0 + 4.0e-6)); // in units of L^2, like the copy
+        const double rt = (p.rc + p.skin) * sc16 + 1.8;                      // test radius in units of L / 65536 (< 2^15: L >= 2 rc)
+        const unsigned int t2 = (unsigned int)__double2uint_rd(rt * rt) + 1u; // accepted: squared separation < t2
         int ovf = 0;
-        __syncthreads(); // the float copy is complete
+        __syncthreads(); // the fixed-point copy is complete
         if constexpr (C::LIST_LDS) {
             // TPA threads per row (the pair loop's grouping): thread (row, sub) tests the contiguous block of candidates
             // j = sub * CH + k, k < CH = ceil(N / TPA) — 32 per round, branch-free, one bit each.  An exclusive scan of the hit
@@ -557,28 +597,30 @@ struct Replica {
             // threads work; the wave-per-row form this replaces kept one wave on a row through 256 candidates with a ballot + mbcnt +
             // scattered byte stores per 64: ~5 us per rebuild of a 256-atom replica at 4 workgroups, as much as an HMC step, 2.4
             // times per move once the chains have equilibrated.
-            // The float copy is read as cf[j + j / 32]: the TPA blocks start 32 apart, and without the skew the candidates a wave
+            // The copy is read as cf[j + j / 32]: the TPA blocks start 32 apart, and without the skew the candidates a wave
             // instruction touches (one per sub) would all sit in one LDS bank.
             const int g = tid / TPA, sub = tid - g * TPA;
             const int CH = (N + TPA - 1) / TPA;
+            IdxT *const nbr_list = nbr_cur();
             for (int i0 = a0; i0 < a1; i0 += G) { // uniform trip count: the scans below need every lane
                 const bool active = i0 + g < a1;
                 const int i = active ? i0 + g : a1 - 1;
-                const float xi = xf[i + (i >> 5)] + 0.5f, yi = yf[i + (i >> 5)] + 0.5f, zi = zf[i + (i >> 5)] + 0.5f;
+                const unsigned long long ci = cf[i + (i >> 5)];
+                const unsigned int xyi = (unsigned int)ci, zi = (unsigned int)(ci >> 32);
                 int base = 0; // entries of the row placed by earlier rounds
                 for (int k0 = 0; k0 < CH; k0 += 32) {
                     unsigned int m = 0u;
                     const int jb = sub * CH + k0;
+                    const int ntest = (min(32, CH - k0) + 7) & ~7; // (16 candidates per thread at 8 workgroups per replica: two groups of eight)
 #pragma unroll 1
-                    for (int b0 = 0; b0 < 32; b0 += 8) // eight tests in flight (unrolled further, the gathers of all 32 are hoisted
-#pragma unroll                                         //  and the kernel, already at its register limit, spills 239 VGPRs)
+                    for (int b0 = 0; b0 < ntest; b0 += 8) // eight tests in flight
+#pragma unroll
                         for (int b = b0; b < b0 + 8; ++b) {
                             const int j = jb + b, js = j + (j >> 5); // (beyond the block or N: whatever lies there, masked below)
-                            // minimum image in units of L: fract(s_i - s_j + 1/2) - 1/2 (three instructions per component)
-                            const float ux = __builtin_amdgcn_fractf(xi - xf[js]) - 0.5f, uy = __builtin_amdgcn_fractf(yi - yf[js]) - 0.5f,
-                                        uz = __builtin_amdgcn_fractf(zi - zf[js]) - 0.5f;
-                            m |= (ux * ux + uy * uy + uz * uz) < rl2 ? (1u << b) : 0u;
+                            const unsigned long long cj = cf[js];
+                            m = test16(m, xyi, zi, (unsigned int)cj, (unsigned int)(cj >> 32), t2);
                         }
+                    m = __brev(m) >> (32 - ntest); // test b sat in bit ntest - 1 - b
                     const int valid = min(32, min(CH - k0, N - jb)); // candidates of this round that exist
                     m &= valid >= 32 ? 0xFFFFFFFFu : valid > 0 ? (1u << valid) - 1u : 0u;
                     if ((unsigned int)(i - jb) < 32u) m &= ~(1u << (i - jb)); // not the atom itself
@@ -591,7 +633,7 @@ struct Replica {
                     while (m) {
                         const int j = jb + (int)__builtin_ctz(m);
                         m &= m - 1u;
-                        if (active && r < MAXNB) nbr[nbr_at(r, i)] = (IdxT)j;
+                        if (active && r < MAXNB) nbr_list[nbr_at(r, i)] = (IdxT)j;
                         ++r;
                     }
                 }
@@ -606,7 +648,8 @@ struct Replica {
             for (int i0 = a0; i0 < a1; i0 += BLOCK) { // one thread per row; uniform trip count: every lane of a wave must take part
                 const bool active = i0 + tid < a1;    // in the candidate loads below (v_readlane reads lanes whatever their exec bit)
                 const int i = active ? i0 + tid : a1 - 1;
-                const float xi = xf[i] + 0.5f, yi = yf[i] + 0.5f, zi = zf[i] + 0.5f;
+                const unsigned long long ci = cf[i];
+                const unsigned int xyi = (unsigned int)ci, zi = (unsigned int)(ci >> 32);
                 int c = 0;
                 unsigned int lo = 0u, hi = 0u; // the chunk being filled: four 16-bit indices
                 for (int j0 = 0; j0 < N; j0 += 64) {
@@ -616,7 +659,8 @@ struct Replica {
                     // divergent branch behind every test (some lane of the wave is in range of nearly every candidate; measured
                     // 5x the arithmetic).
                     const int jl = j0 + lane < N ? j0 + lane : N - 1;
-                    const int cxb = __float_as_int(xf[jl]), cyb = __float_as_int(yf[jl]), czb = __float_as_int(zf[jl]);
+                    const unsigned long long cj = cf[jl];
+                    const int cxy = (int)(unsigned int)cj, cz = (int)(unsigned int)(cj >> 32);
                     unsigned int m0 = 0u, m1 = 0u;
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
@@ -626,12 +670,11 @@ struct Replica {
 #pragma unroll
                             for (int b = b0; b < b0 + 8; ++b) {
                                 const int ln = 32 * half + b;
-                                const float cx = __int_as_float(__builtin_amdgcn_readlane(cxb, ln)), cy = __int_as_float(__builtin_amdgcn_readlane(cyb, ln)),
-                                            cz = __int_as_float(__builtin_amdgcn_readlane(czb, ln));
-                                const float ux = __builtin_amdgcn_fractf(xi - cx) - 0.5f, uy = __builtin_amdgcn_fractf(yi - cy) - 0.5f,
-                                            uz = __builtin_amdgcn_fractf(zi - cz) - 0.5f;
-                                m |= ((ux * ux + uy * uy + uz * uz) < rl2 && j0 + ln < N) ? (1u << b) : 0u;
+                                m = test16(m, xyi, zi, (unsigned int)__builtin_amdgcn_readlane(cxy, ln), (unsigned int)__builtin_amdgcn_readlane(cz, ln), t2);
                             }
+                        m = __brev(m);
+                        const int valid = N - j0 - 32 * half; // candidates of this half that exist
+                        m &= valid >= 32 ? 0xFFFFFFFFu : valid > 0 ? (1u << valid) - 1u : 0u;
                         if (half) m1 = m; else m0 = m;
                     }
                     if ((unsigned int)(i - j0) < 32u) m0 &= ~(1u << (i - j0)); // not the atom itself
@@ -657,6 +700,32 @@ struct Replica {
                 if (active) cnt[i] = (unsigned short)c;
             }
         }
+#ifdef NM_PROF
+        { // diagnostic build: every own row must hold ALL atoms whose exact (fp64, minimum-image) separation is below rc + skin.  The
+          // entries of a row are distinct atoms, so it does iff as many of its entries lie inside that radius as atoms do.
+            __syncthreads();
+            const double rl2 = (p.rc + p.skin) * (p.rc + p.skin), iL = 1.0 / L;
+            for (int i = a0 + tid; i < a1; i += BLOCK) {
+                int n_exact = 0, n_list = 0;
+                auto inside = [&](int j) {
+                    double dx = px[i] - px[j], dy = py[i] - py[j], dz = pz[i] - pz[j];
+                    dx -= L * rint(dx * iL); dy -= L * rint(dy * iL); dz -= L * rint(dz * iL);
+                    return dx * dx + dy * dy + dz * dz < rl2;
+                };
+                for (int j = 0; j < N; ++j) n_exact += (j != i && inside(j)) ? 1 : 0;
+                const int c = cnt[i];
+                for (int r = 0; r < c; ++r) {
+                    int j;
+                    if constexpr (C::LIST_LDS) j = (int)nbr_cur()[nbr_at(r, i)];
+                    else j = (int)((((const unsigned long long *)nbr.ptr())[(size_t)(r >> 2) * NMAX + i] >> (16 * (r & 3))) & 0xFFFFull) >> 3;
+                    n_list += inside(j) ? 1 : 0;
+                }
+                if (n_exact != n_list && c < MAXNB && fabs(px[i]) < 1.0e6 * L && fabs(py[i]) < 1.0e6 * L && fabs(pz[i]) < 1.0e6 * L)
+                    atomicAdd(&nm_list_miss, 1u); // (exploded coordinates — see above — are beyond the exact check's own arithmetic)
+            }
+            __syncthreads();
+        }
+#endif
         for (int i = tid; i < N; i += BLOCK) { x0[i] = px[i]; y0[i] = py[i]; z0[i] = pz[i]; }
         L0 = L;
         flags |= F_LIST_OK;
@@ -803,7 +872,7 @@ struct Replica {
                 if constexpr (C::LIST_LDS) {
                     constexpr int W = NM_PAIR_W, PW = C::PW, BITS = 8 * (int)sizeof(IdxT);
                     static_assert(PW % W == 0, "");
-                    const unsigned long long *nb64 = (const unsigned long long *)nbr.ptr();
+                    const unsigned long long *nb64 = (const unsigned long long *)nbr_cur();
                     const int mine = (c - sub + TPA - 1) / TPA; // neighbours of atom i that this thread handles: slots sub, sub+TPA, ...
                     for (int k0 = 0; k0 < mine; k0 += PW) {     // one conflict-free 8-byte read = PW of them
                         const unsigned long long wd = nb64[((size_t)(k0 >> C::LOG2PW) * C::NLIST + lrow(i)) * TPA + sub];
@@ -1540,8 +1609,8 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
     // pass 1: densities of this workgroup's atoms.  Both passes walk the byte list like pair_loop does: one conflict-free 8-byte
     // read = eight neighbours, two neighbours' dependency chains interleaved stage by stage.
     constexpr int W = NM_PAIR_W;
-    static_assert(sizeof(IdxT) == 1 && C::NLIST == NMAX, "the EAM loops read byte lists with one row per atom");
-    const unsigned long long *nb64 = (const unsigned long long *)nbr.ptr();
+    static_assert(sizeof(IdxT) == 1, "the EAM loops read byte lists");
+    const unsigned long long *nb64 = (const unsigned long long *)nbr_cur();
     for (int i0 = a0; i0 < a1; i0 += G) {
         const int i = i0 + g;
         double r = 0.0;
@@ -1551,7 +1620,7 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
             const int c = cnt[i];
             const int mine = (c - sub + TPA - 1) / TPA;
             for (int k0 = 0; k0 < mine; k0 += 8) {
-                const unsigned long long wd = nb64[((size_t)(k0 >> 3) * NMAX + i) * TPA + sub];
+                const unsigned long long wd = nb64[((size_t)(k0 >> 3) * C::NLIST + lrow(i)) * TPA + sub];
 #pragma unroll
                 for (int e0 = 0; e0 < 8; e0 += W) {
                     if (k0 + e0 == NM_PRIO_SW) prio_swap();
@@ -1632,7 +1701,7 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
             const int c = cnt[i];
             const int mine = (c - sub + TPA - 1) / TPA;
             for (int k0 = 0; k0 < mine; k0 += 8) {
-                const unsigned long long wd = nb64[((size_t)(k0 >> 3) * NMAX + i) * TPA + sub];
+                const unsigned long long wd = nb64[((size_t)(k0 >> 3) * C::NLIST + lrow(i)) * TPA + sub];
 #pragma unroll
                 for (int e0 = 0; e0 < 8; e0 += W) {
                     if (k0 + e0 == NM_PRIO_SW) prio_swap();

@@ -32,14 +32,41 @@ def main():
                     e.set_step(step); e.run_block(12); e.adapt(); e.exchange(count=False)
                 e.synchronize()
                 st = e.stats()
-                n = C.c_uint(0)
-                assert L.nm_prof_oob(e.h, C.byref(n)) == 0
-                acc = e.thermo()
-                print('%d^3 Q=%d %-9s rebuilds %4d  evaluations %5d  out-of-range indices %d'
-                      % (sz, q, 'bulk' if bulk else 'iterative', st[:, 1].sum(), st[:, 0].sum(), n.value), flush=True)
-                total += n.value
+                n, m = C.c_uint(0), C.c_uint(0)
+                assert L.nm_prof_oob(e.h, C.byref(n)) == 0 and L.nm_prof_list_miss(e.h, C.byref(m)) == 0
+                print('%d^3 Q=%d %-9s rebuilds %4d  evaluations %5d  out-of-range indices %d  incomplete list rows %d'
+                      % (sz, q, 'bulk' if bulk else 'iterative', st[:, 1].sum(), st[:, 0].sum(), n.value, m.value), flush=True)
+                total += n.value + m.value
                 e.close()
-    print('TOTAL out-of-range indices: %d' % total)
+    # the 4^3 byte lists (LDS, kept twice), every workgroups-per-replica setting, LJ and the EAM, equilibrated chains incl. the
+    # reference's never-undone iterative trials: every rebuild checked against exact separations
+    T8 = np.linspace(0.25, 2.5, 8, dtype=np.float32)
+    for el, qs in (('LJ', (1, 2, 4, 8)), ('Al', (1, 2, 4))):
+        for q in qs:
+            for bulk in (True, False):
+                os.environ['NM_CUS_PER_REPLICA'] = str(q)
+                Tg = T8 if el == 'LJ' else np.linspace(256.0, 2560.0, 8, dtype=np.float32)
+                Pg = np.linspace(1.0, 8.0, 2, dtype=np.float32)
+                x, v, box, d = lattice.init_states(4, Pg, Tg, 0.03125, 0.03125, el=el)
+                e = nm.Engine(256, Pg, Tg, element=el, bulk=bulk)
+                assert e.cus_per_replica == q
+                e.set_state(x, v, box, d)
+                cycles = 40 if bulk else 10
+                try:
+                    for step in range(cycles):
+                        e.set_step(step); e.run_block(64); e.adapt(); e.exchange(count=False)
+                    e.synchronize()
+                    note = ''
+                except nm.NMError as err:
+                    note = ' [' + str(err)[-60:] + ']'
+                st = e.stats()
+                n, m = C.c_uint(0), C.c_uint(0)
+                assert L.nm_prof_oob(e.h, C.byref(n)) == 0 and L.nm_prof_list_miss(e.h, C.byref(m)) == 0
+                print('4^3 %s Q=%d %-9s rebuilds %5d  evaluations %6d  out-of-range indices %d  incomplete list rows %d%s'
+                      % (el, q, 'bulk' if bulk else 'iterative', st[:, 1].sum(), st[:, 0].sum(), n.value, m.value, note), flush=True)
+                total += n.value + m.value
+                e.close()
+    print('TOTAL out-of-range indices + incomplete list rows: %d' % total)
     return 1 if total else 0
 
 

@@ -2,7 +2,7 @@
 time its blocks took (nm_stats_get column 4: 100 MHz ticks from kernel entry to the exit of the replica's first workgroup) next to
 the work they did, after `warm` cycles of equilibration.
 
-    python scripts/probe_balance.py [config warm cycles]      e.g. C2 30 10
+    python scripts/probe_balance.py [config warm cycles [rows]]      e.g. C2 30 10, or C2 30 10 4 (the first 4 of the preset's rows)
 """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,9 +12,11 @@ from neuralmelting_amd import lattice
 import bench
 
 
-def main(config='C2', warm=30, cycles=10):
+def main(config='C2', warm=30, cycles=10, rows_override=None):
     el, sz, rows, np_cfg, tn, mod, _ = bench.CONFIGS[config]
-    P = np.linspace(1.0, 8.0, rows, dtype=np.float32)
+    if rows_override:   # a share of the preset's grid: its first `rows_override` pressure rows
+        rows = rows_override
+    P = np.linspace(1.0, 8.0, np_cfg if rows_override else rows, dtype=np.float32)
     T = np.linspace(0.25, 2.5, tn, dtype=np.float32) if el == 'LJ' else np.linspace(256.0, 2560.0, tn, dtype=np.float32)
     x, v, box, d = lattice.init_states(sz, P, T, 0.03125, 0.03125, el=el, row0=0, nrows=rows)
     e = nm.Engine(4 * sz ** 3, P, T, element=el, row0=0, nrows=rows)
@@ -48,4 +50,4 @@ def main(config='C2', warm=30, cycles=10):
 
 if __name__ == '__main__':
     a = sys.argv[1:]
-    main(a[0] if a else 'C2', int(a[1]) if len(a) > 1 else 30, int(a[2]) if len(a) > 2 else 10)
+    main(a[0] if a else 'C2', int(a[1]) if len(a) > 1 else 30, int(a[2]) if len(a) > 2 else 10, int(a[3]) if len(a) > 3 else None)
