@@ -251,7 +251,7 @@ def main():
 
         win = numbers(dt_w, launches_w, kms_w, st_w)
         sus = numbers(dt, launches, kms, st) if args.equil > 0 else win
-        prof = measured_profile(args.config if not custom else None, ns, mod)
+        prof = measured_profile((args.config + ('_iter' if args.iterative else '')) if not custom else None, ns, mod)
         grid = '%dx%d PxT grid%s' % (npn, tn, '' if world == 1 else ' over %d GPUs' % world)
         metric = 'MC sweeps/sec (whole node), %s %d^3 cells, %s' % (el, sz, grid)
         out = {

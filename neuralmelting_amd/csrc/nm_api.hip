@@ -941,6 +941,13 @@ int nm_prof_list_miss(nm_ctx *c, unsigned int *count)
     HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(nm::nm_list_miss), &zero, sizeof(unsigned int)));
     return NM_OK;
 }
+int nm_prof_miss_info(nm_ctx *c, double *info16)
+{
+    if (!c || !info16) return NM_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyFromSymbol(info16, HIP_SYMBOL(nm::nm_miss_info), 16 * sizeof(double)));
+    return NM_OK;
+}
 // diagnostic build only: cycle sums per section and slot, [nslots][16]
 int nm_prof_get(nm_ctx *c, unsigned long long *out, int reset)
 {

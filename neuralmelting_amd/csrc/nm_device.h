@@ -200,22 +200,27 @@ __device__ __forceinline__ double wave_sum(double v)
 // Sum NV values over the workgroup; every thread returns the same bits (fixed order: butterfly inside a
 // wave, then waves 0..NW-1).  `red` has 2*NW*NVMAX doubles and is used in two alternating halves so that
 // one barrier per reduction suffices.
+// nact: waves 0 .. nact-1 may hold non-zero addends (a sum over N < BLOCK items dealt out by thread index); the others skip the
+// butterflies — sixteen of them in velocity_create, on SIMDs they share with the waves that do have work — and are left out of
+// the second stage.  Adding their zeros or not gives the same bits.
 template <int NV, int NW, int NVMAX>
-__device__ __forceinline__ void block_sum(double (&v)[NV], double *red, int &parity)
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *red, int &parity, int nact = NW)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double *r = red + parity * (NW * NVMAX);
+    if (wv < nact) {
 #pragma unroll
-    for (int q = 0; q < NV; ++q) {
-        const double s = wave_sum(v[q]);
-        if (lane == 0) r[wv * NVMAX + q] = s;
+        for (int q = 0; q < NV; ++q) {
+            const double s = wave_sum(v[q]);
+            if (lane == 0) r[wv * NVMAX + q] = s;
+        }
     }
     __syncthreads();
-    // second stage: lane q < NV of every wave adds the NW partial sums of value q (NW reads instead of NW*NV per thread), then
+    // second stage: lane q < NV of every wave adds the partial sums of value q (NW reads instead of NW*NV per thread), then
     // the totals are handed to all lanes through v_readlane: scalar registers, the same bits everywhere
     double s = 0.0;
     if (lane < NV)
-        for (int w = 0; w < NW; ++w) s += r[w * NVMAX + lane];
+        for (int w = 0; w < nact; ++w) s += r[w * NVMAX + lane];
     const long long sb = __double_as_longlong(s);
 #pragma unroll
     for (int q = 0; q < NV; ++q) {

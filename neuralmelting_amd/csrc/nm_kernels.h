@@ -15,6 +15,9 @@
 
 namespace nm {
 
+#ifndef NM_AB
+#define NM_AB 0 // A/B experiments: a variant library is built with -DNM_AB=k (scripts/ab_multi.sh), the shipped one with 0
+#endif
 #ifndef NM_PAIR_W
 #define NM_PAIR_W 2 // listed neighbours a thread works on at once (pair_vec)
 #endif
@@ -71,6 +74,7 @@ struct LdsArr {
 // (nm_oob_count, read by nm_prof_oob) and redirected to element 0, so the diagnostic run itself cannot fault.
 __device__ unsigned int nm_oob_count;
 __device__ unsigned int nm_list_miss; // rows of a freshly built list that lack an atom inside rc + skin (Replica::rebuild's self-check)
+__device__ double nm_miss_info[16];    // details of the first such row
 #define NM_BOUND(arr, count) (arr).n = (size_t)(count)
 #define NM_CHECK_INDEX(i, count) ((size_t)(i) < (size_t)(count) ? (size_t)(i) : (atomicAdd(&nm_oob_count, 1u), (size_t)0))
 #else
@@ -141,7 +145,11 @@ struct Cfg {
     // One workgroup per CU, by construction: a cluster's census and the Q selection count on it (nm_probe_kernel asserts it), and
     // two workgroups of different replicas on one CU measured slower.  A configuration that would fit twice
     // into the CU's 160 KB asks for a little more than half of them.
+#if NM_AB == 4 // experiment: 8 workgroups per replica, two (of different replicas) per CU
+    static constexpr size_t LDS_BYTES = (TPA_ == 16 || LDS_NATURAL > (size_t)82 * 1024) ? LDS_NATURAL : (size_t)82 * 1024;
+#else
     static constexpr size_t LDS_BYTES = LDS_NATURAL > (size_t)82 * 1024 ? LDS_NATURAL : (size_t)82 * 1024;
+#endif
     // per-slot global spill when the saved copies do not fit in LDS: sav, savv, x0 (9 NMAX doubles) + images + wrap counts
     static constexpr size_t AUX_SAVES = SAVE_LDS ? (SAVEV_LDS ? 0 : (size_t)3 * NMAX) : (size_t)9 * NMAX + ((size_t)3 * NMAX * 3 + 7) / 8;
     // lists outside LDS are kept TWICE per slot (LIST2): a trial that rebuilt and is then rejected goes back to the list it started
@@ -226,7 +234,11 @@ __device__ __attribute__((noinline)) double velocity_create(double t, uint32_t t
         a[14] -= m * Y * Z;
         a[15] -= m * X * Z;
     }
+#if NM_AB == 1
     block_sum<16, NW, NVMAX>(a, red, parity);
+#else
+    block_sum<16, NW, NVMAX>(a, red, parity, min(NW, (N + 63) >> 6)); // (atoms are dealt out by thread index: N <= 256 leaves half the waves empty)
+#endif
     const double c0 = a[0] / mt, c1 = a[1] / mt, c2 = a[2] / mt;   // COM velocity
     const double cx = a[3] / mt, cy = a[4] / mt, cz = a[5] / mt;   // centre of mass (unwrapped)
     const double dof = 3.0 * N - 3.0;
@@ -522,24 +534,109 @@ struct Replica {
     }
 
     // One candidate test of the list rebuild on 16-bit fixed-point coordinates (units of L / 65536): xy holds x | y << 16, z the
-    // third coordinate.  v_pk_sub_i16 wraps modulo 2^16, which IS the minimum image; two v_dot2 give the squared separation (at most
-    // 3 x 2^30: no wrap as an unsigned 32-bit number); the compare's carry is shifted into the mask by v_addc (m + m + carry), so a
-    // test is six VALU instructions.  The result of the b-th test of a run of 32 ends up in bit 31 - b (the callers reverse).
+    // third coordinate.  v_pk_sub_i16 wraps modulo 2^16, which IS the minimum image; three v_mad_i32_i16 (the second on the high
+    // halves) give the squared separation (at most 3 x 2^30: no wrap as an unsigned 32-bit number); the compare's carry is shifted
+    // into the mask by v_addc (m + m + carry): seven VALU instructions per test (scripts/ubench_int16.hip: 36 cycles per wave, 48
+    // with two v_dot2c_i32_i16 and the wait states a dot product's result needs before another instruction may read it — which
+    // hipcc does not insert for a reader inside an asm statement, so the dot form is not used).  The result of the b-th test of a
+    // run ends up in bit n - 1 - b (the callers reverse).
     typedef short v2s16 __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ unsigned int test16(unsigned int m, unsigned int xyi, unsigned int zi, unsigned int xyj, unsigned int zj,
                                                           unsigned int t2)
     {
-        const v2s16 d0 = __builtin_bit_cast(v2s16, xyi) - __builtin_bit_cast(v2s16, xyj);
-        const v2s16 d1 = __builtin_bit_cast(v2s16, zi) - __builtin_bit_cast(v2s16, zj);
-        int r = __builtin_amdgcn_sdot2(d0, d0, 0, false);
-        r = __builtin_amdgcn_sdot2(d1, d1, r, false);
-        asm("v_cmp_gt_u32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(r), "v"(t2) : "vcc");
+        const unsigned int d0 = __builtin_bit_cast(unsigned int, (v2s16)(__builtin_bit_cast(v2s16, xyi) - __builtin_bit_cast(v2s16, xyj)));
+        const unsigned int d1 = __builtin_bit_cast(unsigned int, (v2s16)(__builtin_bit_cast(v2s16, zi) - __builtin_bit_cast(v2s16, zj)));
+        unsigned int r;
+        asm("v_mad_i32_i16 %1, %2, %2, 0\n\t"
+            "v_mad_i32_i16 %1, %2, %2, %1 op_sel:[1,1,0,0]\n\t"
+            "v_mad_i32_i16 %1, %3, %3, %1\n\t"
+            "v_cmp_gt_u32 vcc, %4, %1\n\t"
+            "v_addc_co_u32 %0, vcc, %0, %0, vcc"
+            : "+v"(m), "=&v"(r) : "v"(d0), "v"(d1), "v"(t2) : "vcc");
         return m;
+    }
+
+    // rows ibase + tid (and ibase + BLOCK + tid) of a list that lives in HBM/L2: 64 candidates per block.  Each lane fetches ONE of
+    // them (a coalesced read), and the block is then walked with v_readlane: a candidate's coordinates reach all lanes as scalar
+    // operands, no LDS access and no load latency per candidate.  The tests are branch-free, one bit each: appending inside this
+    // loop would put a divergent branch behind every test (some lane of the wave is in range of nearly every candidate; measured 5x
+    // the arithmetic).  A thread packs four indices into the 8-byte chunk the pair loop reads and stores it whole.
+    template <int NR>
+    __device__ __forceinline__ void rebuild_rows_hbm(int ibase, const unsigned long long *cf, unsigned int t2, int &ovf)
+    {
+        const int lane = tid & 63;
+        unsigned long long *g = (unsigned long long *)nbr.ptr();
+        bool active[NR];
+        int i[NR], c[NR];
+        unsigned int xyi[NR], zi[NR], lo[NR], hi[NR]; // lo, hi: the chunk being filled, four 16-bit indices
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            active[r] = ibase + r * BLOCK + tid < a1;
+            i[r] = active[r] ? ibase + r * BLOCK + tid : a1 - 1;
+            const unsigned long long ci = cf[i[r]];
+            xyi[r] = (unsigned int)ci; zi[r] = (unsigned int)(ci >> 32);
+            c[r] = 0; lo[r] = hi[r] = 0u;
+        }
+        for (int j0 = 0; j0 < N; j0 += 64) {
+            const int jl = j0 + lane < N ? j0 + lane : N - 1;
+            const unsigned long long cj = cf[jl];
+            const int cxy = (int)(unsigned int)cj, cz = (int)(unsigned int)(cj >> 32);
+            unsigned int mm[NR][2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                unsigned int m[NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) m[r] = 0u;
+#pragma unroll 1
+                for (int b0 = 0; b0 < 32; b0 += 8) // eight candidates in flight; unrolled further the kernel spills more than it gains
+#pragma unroll
+                    for (int b = b0; b < b0 + 8; ++b) {
+                        const int ln = 32 * half + b;
+                        const unsigned int sxy = (unsigned int)__builtin_amdgcn_readlane(cxy, ln), sz_ = (unsigned int)__builtin_amdgcn_readlane(cz, ln);
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) m[r] = test16(m[r], xyi[r], zi[r], sxy, sz_, t2);
+                    }
+                const int valid = N - j0 - 32 * half; // candidates of this half that exist
+                const unsigned int vm = valid >= 32 ? 0xFFFFFFFFu : valid > 0 ? (1u << valid) - 1u : 0u;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) mm[r][half] = __brev(m[r]) & vm;
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                if ((unsigned int)(i[r] - j0) < 32u) mm[r][0] &= ~(1u << (i[r] - j0)); // not the atom itself
+                else if ((unsigned int)(i[r] - j0) < 64u) mm[r][1] &= ~(1u << (i[r] - j0 - 32));
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    unsigned int m = mm[r][half];
+                    while (m) { // a few bits per thread and block
+                        const unsigned int j = (unsigned int)(j0 + 32 * half + __builtin_ctz(m));
+                        m &= m - 1u;
+                        if (c[r] < MAXNB) {
+                            const unsigned int v = (j << 3) << (16 * (c[r] & 1)); // the entry is the byte offset 8 j (pair_vec<.., BYTES>)
+                            if (c[r] & 2) hi[r] |= v; else lo[r] |= v;
+                            if ((c[r] & 3) == 3) {
+                                if (active[r]) g[NM_CHECK_INDEX((size_t)(c[r] >> 2) * NMAX + i[r], C::NBR_G_ELEMS / 4)] = ((unsigned long long)hi[r] << 32) | lo[r];
+                                lo[r] = hi[r] = 0u;
+                            }
+                        }
+                        ++c[r];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (active[r] && c[r] < MAXNB && (c[r] & 3)) // the last, partial chunk
+                g[NM_CHECK_INDEX((size_t)(c[r] >> 2) * NMAX + i[r], C::NBR_G_ELEMS / 4)] = ((unsigned long long)hi[r] << 32) | lo[r];
+            st_maxc = max(st_maxc, c[r]);
+            if (c[r] > MAXNB) { ovf = 1; c[r] = MAXNB; }
+            if (active[r]) cnt[i[r]] = (unsigned short)c[r];
+        }
     }
 
     // Verlet-list rebuild.
     // * The candidate test runs on a 16-bit fixed-point copy of the positions, u = round(65536 x / L) mod 2^16 per coordinate (round 3;
-    //   fp32 in round 2, fp64 in round 1): VALU issue bounds the build, and in this form a test is six instructions (test16) against
+    //   fp32 in round 2, fp64 in round 1): VALU issue bounds the build, and in this form a test is seven instructions (test16) against
     //   fourteen to eighteen in fp32.  The copy lives in the force array, which is dead here: every caller of rebuild() is about to
     //   run the pair loop that rewrites it.  Each coordinate is off by at most half a unit, each component of a separation by one,
     //   the separation itself by at most sqrt(3) units: the test radius is rc + skin + 1.8 units (1.7e-4 at L = 6.1, 3.4e-4 at
@@ -644,70 +741,24 @@ struct Replica {
         } else {
             static_assert(C::CH == 4 && sizeof(IdxT) == 2 && MAXNB % 4 == 0, "four 16-bit indices per 8-byte chunk");
             static_assert((size_t)NMAX * 8 <= 65536, "the entries hold 8 x the atom index");
-            unsigned long long *g = (unsigned long long *)nbr.ptr();
-            for (int i0 = a0; i0 < a1; i0 += BLOCK) { // one thread per row; uniform trip count: every lane of a wave must take part
-                const bool active = i0 + tid < a1;    // in the candidate loads below (v_readlane reads lanes whatever their exec bit)
-                const int i = active ? i0 + tid : a1 - 1;
-                const unsigned long long ci = cf[i];
-                const unsigned int xyi = (unsigned int)ci, zi = (unsigned int)(ci >> 32);
-                int c = 0;
-                unsigned int lo = 0u, hi = 0u; // the chunk being filled: four 16-bit indices
-                for (int j0 = 0; j0 < N; j0 += 64) {
-                    // 64 candidates per block.  Each lane fetches ONE of them (a coalesced read), and the block is then walked
-                    // with v_readlane: a candidate's coordinates reach all lanes as scalar operands, no LDS access and no load
-                    // latency per candidate.  The tests are branch-free, one bit each: appending inside this loop would put a
-                    // divergent branch behind every test (some lane of the wave is in range of nearly every candidate; measured
-                    // 5x the arithmetic).
-                    const int jl = j0 + lane < N ? j0 + lane : N - 1;
-                    const unsigned long long cj = cf[jl];
-                    const int cxy = (int)(unsigned int)cj, cz = (int)(unsigned int)(cj >> 32);
-                    unsigned int m0 = 0u, m1 = 0u;
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        unsigned int m = 0u;
-#pragma unroll 1
-                        for (int b0 = 0; b0 < 32; b0 += 8) // eight tests in flight; unrolled further the kernel spills more than it gains
-#pragma unroll
-                            for (int b = b0; b < b0 + 8; ++b) {
-                                const int ln = 32 * half + b;
-                                m = test16(m, xyi, zi, (unsigned int)__builtin_amdgcn_readlane(cxy, ln), (unsigned int)__builtin_amdgcn_readlane(cz, ln), t2);
-                            }
-                        m = __brev(m);
-                        const int valid = N - j0 - 32 * half; // candidates of this half that exist
-                        m &= valid >= 32 ? 0xFFFFFFFFu : valid > 0 ? (1u << valid) - 1u : 0u;
-                        if (half) m1 = m; else m0 = m;
-                    }
-                    if ((unsigned int)(i - j0) < 32u) m0 &= ~(1u << (i - j0)); // not the atom itself
-                    else if ((unsigned int)(i - j0) < 64u) m1 &= ~(1u << (i - j0 - 32));
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        unsigned int m = half ? m1 : m0;
-                        while (m) { // a few bits per thread and block
-                            const unsigned int j = (unsigned int)(j0 + 32 * half + __builtin_ctz(m));
-                            m &= m - 1u;
-                            if (c < MAXNB) {
-                                const unsigned int v = (j << 3) << (16 * (c & 1)); // the entry is the byte offset 8 j (pair_vec<.., BYTES>)
-                                if (c & 2) hi |= v; else lo |= v;
-                                if ((c & 3) == 3) { if (active) g[NM_CHECK_INDEX((size_t)(c >> 2) * NMAX + i, C::NBR_G_ELEMS / 4)] = ((unsigned long long)hi << 32) | lo; lo = hi = 0u; }
-                            }
-                            ++c;
-                        }
-                    }
-                }
-                if (active && c < MAXNB && (c & 3)) g[NM_CHECK_INDEX((size_t)(c >> 2) * NMAX + i, C::NBR_G_ELEMS / 4)] = ((unsigned long long)hi << 32) | lo; // the last, partial chunk
-                st_maxc = max(st_maxc, c);
-                if (c > MAXNB) { ovf = 1; c = MAXNB; }
-                if (active) cnt[i] = (unsigned short)c;
+            // one thread per row, two rows at a time where a thread has two (rows i and i + BLOCK): the candidate's two v_readlane
+            // serve both tests.  Uniform trip count: every lane of a wave must take part in the candidate loads (v_readlane reads
+            // lanes whatever their exec bit).
+            for (int i0 = a0; i0 < a1; i0 += 2 * BLOCK) {
+                if (i0 + BLOCK + (tid & ~63) < a1) rebuild_rows_hbm<2>(i0, cf, t2, ovf); // (wave-uniform)
+                else rebuild_rows_hbm<1>(i0, cf, t2, ovf);
             }
         }
 #ifdef NM_PROF
-        { // diagnostic build: every own row must hold ALL atoms whose exact (fp64, minimum-image) separation is below rc + skin.  The
-          // entries of a row are distinct atoms, so it does iff as many of its entries lie inside that radius as atoms do.
+        if (p.dbg & 8) { // diagnostic build, NM_DBG=8 (scripts/check_bounds.py; off for the section timings of the same build): every own
+            // row must hold ALL atoms whose exact (fp64, minimum-image) separation is below rc + skin.  The entries of a row are distinct
+            // atoms, so it does iff as many of its entries lie inside that radius as atoms do.
             __syncthreads();
             const double rl2 = (p.rc + p.skin) * (p.rc + p.skin), iL = 1.0 / L;
             for (int i = a0 + tid; i < a1; i += BLOCK) {
                 int n_exact = 0, n_list = 0;
                 auto inside = [&](int j) {
+                    if (!(fabs(px[j]) < 1.0e6 * L && fabs(py[j]) < 1.0e6 * L && fabs(pz[j]) < 1.0e6 * L)) return false; // (see below)
                     double dx = px[i] - px[j], dy = py[i] - py[j], dz = pz[i] - pz[j];
                     dx -= L * rint(dx * iL); dy -= L * rint(dy * iL); dz -= L * rint(dz * iL);
                     return dx * dx + dy * dy + dz * dz < rl2;
@@ -720,8 +771,30 @@ struct Replica {
                     else j = (int)((((const unsigned long long *)nbr.ptr())[(size_t)(r >> 2) * NMAX + i] >> (16 * (r & 3))) & 0xFFFFull) >> 3;
                     n_list += inside(j) ? 1 : 0;
                 }
-                if (n_exact != n_list && c < MAXNB && fabs(px[i]) < 1.0e6 * L && fabs(py[i]) < 1.0e6 * L && fabs(pz[i]) < 1.0e6 * L)
-                    atomicAdd(&nm_list_miss, 1u); // (exploded coordinates — see above — are beyond the exact check's own arithmetic)
+                if (n_exact != n_list && c < MAXNB && fabs(px[i]) < 1.0e6 * L && fabs(py[i]) < 1.0e6 * L && fabs(pz[i]) < 1.0e6 * L) {
+                    // (exploded coordinates — see above — are beyond the exact check's own arithmetic)
+                    if (atomicAdd(&nm_list_miss, 1u) == 0u) { // the first one: which atom is missing, and how far away it is
+                        int jm = -1;
+                        for (int j = 0; j < N && jm < 0; ++j) {
+                            if (j == i || !inside(j)) continue;
+                            bool listed = false;
+                            for (int r = 0; r < c; ++r) {
+                                int jj;
+                                if constexpr (C::LIST_LDS) jj = (int)nbr_cur()[nbr_at(r, i)];
+                                else jj = (int)((((const unsigned long long *)nbr.ptr())[(size_t)(r >> 2) * NMAX + i] >> (16 * (r & 3))) & 0xFFFFull) >> 3;
+                                listed = listed || jj == j;
+                            }
+                            if (!listed) jm = j;
+                        }
+                        double *o = nm_miss_info;
+                        o[0] = gslot; o[1] = i; o[2] = jm; o[3] = n_exact; o[4] = n_list; o[5] = c; o[6] = L; o[7] = p.rc + p.skin;
+                        if (jm >= 0) {
+                            o[8] = px[i]; o[9] = py[i]; o[10] = pz[i]; o[11] = px[jm]; o[12] = py[jm]; o[13] = pz[jm];
+                            const unsigned long long ci = cf[C::LIST_LDS ? i + (i >> 5) : i], cj = cf[C::LIST_LDS ? jm + (jm >> 5) : jm];
+                            o[14] = (double)ci; o[15] = (double)cj;
+                        }
+                    }
+                }
             }
             __syncthreads();
         }
@@ -1827,7 +1900,9 @@ __device__ __forceinline__ bool residency_census(const KParams &p)
 template <class C>
 __global__ void __launch_bounds__(C::BLOCK) nm_probe_kernel(const KParams p)
 {
+#if NM_AB != 4
     static_assert(2 * C::LDS_BYTES > 160 * 1024, "the probe stands in for the block kernel only while LDS limits both to one workgroup per CU");
+#endif
     const int Q = p.cus, b = blockIdx.x;
     int slot;
     if ((p.nslots & 7) == 0) slot = (b & 7) + 8 * ((b >> 3) / Q); else slot = b / Q;

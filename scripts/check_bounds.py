@@ -10,6 +10,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
+os.environ['NM_DBG'] = '8'   # switches the exact list self-check of the diagnostic build on
+
 
 def main():
     import neuralmelting_amd as nm
@@ -64,6 +66,15 @@ def main():
                 assert L.nm_prof_oob(e.h, C.byref(n)) == 0 and L.nm_prof_list_miss(e.h, C.byref(m)) == 0
                 print('4^3 %s Q=%d %-9s rebuilds %5d  evaluations %6d  out-of-range indices %d  incomplete list rows %d%s'
                       % (el, q, 'bulk' if bulk else 'iterative', st[:, 1].sum(), st[:, 0].sum(), n.value, m.value, note), flush=True)
+                if m.value:
+                    info = np.zeros(16)
+                    L.nm_prof_miss_info(e.h, info.ctypes.data_as(C.POINTER(C.c_double)))
+                    print('    first incomplete row: slot %d atom %d lacks atom %d; exact count %d, listed inside %d, row length %d, L %.6f, radius %.3f'
+                          % tuple(info[:8]))
+                    if info[2] >= 0:
+                        xi, xj, Lb = info[8:11], info[11:14], info[6]
+                        dd = xi - xj; dd -= Lb * np.rint(dd / Lb)
+                        print('    x_i', xi, 'x_j', xj, 'separation %.9f' % np.sqrt((dd * dd).sum()), 'fixed i %x j %x' % (int(info[14]), int(info[15])))
                 total += n.value + m.value
                 e.close()
     print('TOTAL out-of-range indices + incomplete list rows: %d' % total)

@@ -18,6 +18,8 @@ def main():
     ap.add_argument('--mod', type=int, default=None)
     ap.add_argument('--commit', default=None)
     ap.add_argument('--skip', type=int, default=0, help='launches to drop from the front (warm-up)')
+    ap.add_argument('--take', type=int, default=0, help='launches to keep after the skipped ones (0 = all)')
+    ap.add_argument('--regime', default=None, help="what the kept launches are, e.g. 'equilibrated: cycles 30-39 after the lattice start'")
     a = ap.parse_args()
     per = defaultdict(lambda: defaultdict(float))           # counter -> dispatch -> value (summed over XCDs / instances)
     for d in a.dirs:
@@ -28,8 +30,11 @@ def main():
     res = {}
     for c, v in sorted(per.items()):
         vals = [v[k] for k in sorted(v)][a.skip:]
+        if a.take:
+            vals = vals[:a.take]
         res[c] = {'launches': len(vals), 'mean': sum(vals) / len(vals), 'min': min(vals), 'max': max(vals)}
-    res['_meta'] = {'commit': a.commit, 'config': a.config, 'replicas': a.replicas, 'mod': a.mod, 'kernel': a.kernel}
+    res['_meta'] = {'commit': a.commit, 'config': a.config, 'replicas': a.replicas, 'mod': a.mod, 'kernel': a.kernel, 'regime': a.regime,
+                    'launches_skipped': a.skip}
     json.dump(res, open(a.out, 'w'), indent=1)
     print(json.dumps(res))
 

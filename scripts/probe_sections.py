@@ -8,13 +8,13 @@ import neuralmelting_amd as nm
 from neuralmelting_amd import lattice, _lib
 
 NAMES = ['eval:entry barrier', 'eval:list check', 'eval:rebuild', 'eval:pair loop', 'eval:reduce/barrier',
-         'post:init', 'post:bulk', 'post:vmc', 'post:hmc start', 'post:hmc step', 'pre:bulk', 'pre:vmc', 'pre:hmc', 'iter pmc', 'eval:cluster exchange', '-']
+         'post:init', 'post:bulk', 'post:vmc', 'post:hmc start', 'post:hmc step + hand-over', 'pre:bulk', 'pre:vmc', 'pre:hmc', 'iter pmc', 'eval:cluster exchange', '-']
 
 def main(sz=4, rows=8, tn=8, mod=128, cycles=3, warm=6):
     npn = int(os.environ.get('NP_ALL', rows))
     P = np.linspace(1, 8, npn, dtype=np.float32); T = np.linspace(.25, 2.5, tn, dtype=np.float32)
     x, v, box, d = lattice.init_states(sz, P, T, 0.03125, 0.03125, row0=0, nrows=rows)
-    e = nm.Engine(4 * sz ** 3, P, T, row0=0, nrows=rows)
+    e = nm.Engine(4 * sz ** 3, P, T, row0=0, nrows=rows, bulk=os.environ.get('NM_PROBE_ITER') != '1')  # NM_PROBE_ITER=1: iterative position moves
     e.set_state(x, v, box, d)
     L = _lib.load()
     L.nm_prof_get.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
