@@ -154,6 +154,9 @@ void fill_params(const nm_ctx *c, KParams &p)
     p.status_acc = c->d_status_acc; p.halt = c->d_halt; p.rerun_mask = nullptr; p.inj_census = 0;
 }
 
+// workgroups of a launch: 8 Q ceil(nslots / 8), the block kernel's cluster mapping (nm_kernels.h); nslots x Q when 8 divides nslots or Q = 1
+unsigned int nm_grid(int nslots, int q) { return q == 1 ? (unsigned int)nslots : (unsigned int)(8 * q * ((nslots + 7) / 8)); }
+
 template <class C>
 hipError_t launch_block(const nm_ctx *c, const KParams &p)
 {
@@ -161,7 +164,7 @@ hipError_t launch_block(const nm_ctx *c, const KParams &p)
         const hipError_t e = hipMemsetAsync(c->d_census, 0, sizeof(unsigned int), c->stream);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(nm_block_kernel<C>, dim3(c->nslots * c->cus), dim3(C::BLOCK), C::LDS_BYTES, c->stream, p);
+    hipLaunchKernelGGL(nm_block_kernel<C>, dim3(nm_grid(c->nslots, c->cus)), dim3(C::BLOCK), C::LDS_BYTES, c->stream, p);
     return hipGetLastError();
 }
 
@@ -172,7 +175,7 @@ hipError_t launch_probe(const nm_ctx *c, const KParams &p)
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(c->d_census, 0, sizeof(unsigned int), c->stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(nm_probe_kernel<C>, dim3(c->nslots * c->cus), dim3(C::BLOCK), C::LDS_BYTES, c->stream, p);
+    hipLaunchKernelGGL(nm_probe_kernel<C>, dim3(nm_grid(c->nslots, c->cus)), dim3(C::BLOCK), C::LDS_BYTES, c->stream, p);
     return hipGetLastError();
 }
 
@@ -335,7 +338,7 @@ int pick_q(nm_ctx *c, int qmax, std::string &note)
     for (int qq : { 8, 4, 2 }) {
         if (qq > maxq || qq > qmax) continue;
         const int per_cu = blocks_per_cu_kind(c->kind, c->pot, qq);
-        if ((long)c->nslots * qq > (long)per_cu * cu) continue;
+        if ((long)nm_grid(c->nslots, qq) > (long)per_cu * cu) continue;
         c->cus = qq; // probe: does the grid of this Q gather?
         KParams p;
         fill_params(c, p);
@@ -350,7 +353,7 @@ int pick_q(nm_ctx *c, int qmax, std::string &note)
         HIPCHK(c, hipMemset(c->d_status, 0, sizeof(int) * c->nslots));
         if (ok) return NM_OK;
         char buf[200];
-        std::snprintf(buf, sizeof buf, "%d workgroups per replica (%d in all) did not gather on this device; falling back. ", qq, c->nslots * qq);
+        std::snprintf(buf, sizeof buf, "%d workgroups per replica (%d in all) did not gather on this device; falling back. ", qq, (int)nm_grid(c->nslots, qq));
         note += buf;
         c->cus = 1;
     }

@@ -1904,9 +1904,8 @@ __global__ void __launch_bounds__(C::BLOCK) nm_probe_kernel(const KParams p)
     static_assert(2 * C::LDS_BYTES > 160 * 1024, "the probe stands in for the block kernel only while LDS limits both to one workgroup per CU");
 #endif
     const int Q = p.cus, b = blockIdx.x;
-    int slot;
-    if ((p.nslots & 7) == 0) slot = (b & 7) + 8 * ((b >> 3) / Q); else slot = b / Q;
-    if (!residency_census<C>(p) && threadIdx.x == 0) atomicOr(&p.status[slot], (int)ST_NOT_RESIDENT);
+    const int slot = (b & 7) + 8 * ((b >> 3) / Q); // (the block kernel's mapping; a padding workgroup takes the census and leaves)
+    if (!residency_census<C>(p) && threadIdx.x == 0 && slot < p.nslots) atomicOr(&p.status[slot], (int)ST_NOT_RESIDENT);
 }
 
 // Phases of the per-replica state machine.  The block kernel is written so that eval() — by far the largest
@@ -1921,19 +1920,23 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
 {
     constexpr int BLOCK = C::BLOCK;
     const unsigned long long t_entry = wall_clock64(); // (stats column 4)
-    // cluster mapping: with 8 | nslots the Q members of a cluster share blockIdx % 8, i.e. one XCD (and its L2) under the
-    // observed round-robin placement — a speed matter only, the hand-off protocol does not depend on it
+    // Cluster mapping: the Q members of a cluster share blockIdx % 8, i.e. one XCD (and its L2) under the observed round-robin
+    // placement — slot x + 8 s takes the workgroups x + 8 (s Q + q), q < Q.  The grid is 8 Q ceil(nslots / 8) workgroups (nm_grid):
+    // when 8 does not divide nslots the workgroups of the slots that do not exist only take the census and leave.  (Round 2 mapped
+    // such grids slot = b / Q, which spread every cluster over all XCDs: write-through hand-overs, ~0.5 us more per hop.)
     const int Q = p.cus, b = blockIdx.x;
-    int slot, qq;
-    if ((p.nslots & 7) == 0) { const int r = b >> 3; slot = (b & 7) + 8 * (r / Q); qq = r % Q; }
-    else { slot = b / Q; qq = b % Q; }
+    const int r_ = b >> 3, slot = (b & 7) + 8 * (r_ / Q), qq = r_ % Q;
+    if (halted(p)) return; // an earlier block stopped on an error: nothing runs on its state until the host has dealt with it
+    if (slot >= p.nslots) { // padding workgroup
+        if (Q > 1 && p.census) (void)residency_census<C>(p);
+        return;
+    }
     const int buf = p.slot2buf[slot];
     const int tid = threadIdx.x;
     Replica<C> R(p, slot, qq);
     const bool writer = (tid == 0 && qq == 0); // one workgroup of the cluster writes the replica's results
     const int N = p.N;
 
-    if (halted(p)) return; // an earlier block stopped on an error: nothing runs on its state until the host has dealt with it
     if (Q > 1 && p.census && !residency_census<C>(p)) { // nothing has been touched yet
         if (writer) report_status(p, slot, ST_NOT_RESIDENT, true);
         return;
