@@ -66,6 +66,8 @@ def main():
         # 733-737): from about cycle 10 on atoms overlap, energies reach 1e12-1e18 per atom and sooner or later leave the floating-point
         # range (NM_ST_NONFINITE; LAMMPS would stop the reference there).  That mode has no equilibrated regime to time: window only.
         args.equil = 0
+        if (args.warmup, args.steps) == (ap.get_default('warmup'), ap.get_default('steps')):
+            args.warmup, args.steps = 3, 5   # cycles 3-7: before the chains leave the floating-point range
 
     el, sz, rows, np_cfg, tn, mod, desc = CONFIGS[args.config]
     custom = any(v is not None for v in (args.sz, args.rows, args.tn, args.mod, args.el))

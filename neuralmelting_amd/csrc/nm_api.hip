@@ -29,8 +29,16 @@ namespace {
 // cluster variants of the small kernel: Q workgroups per replica, threads-per-atom scaled so that all 512 threads work
 // (a cluster stores the list rows of its own atoms only, and keeps the list twice: a rejected move goes back to the one it started from)
 typedef Cfg<NM_SMALL_BLOCK, 2 * NM_SMALL_TPA, 256, 192, unsigned char, true, true, 0, 128, true, true> CfgSmallQ2;
+#if NM_SMALL_BLOCK == 1024
+typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 256, unsigned char, true, true, 0, 64, true, true> CfgSmallQ4;
+#else
 typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 192, unsigned char, true, true, 0, 64, true, true> CfgSmallQ4;
+#endif
+#if NM_SMALL_BLOCK == 1024 // (experiment: 16 waves per workgroup; 32 threads per row would not fit a DPP row)
+typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 256, unsigned char, true, true, 0, 64, true, true> CfgSmallQ8;
+#else
 typedef Cfg<NM_SMALL_BLOCK, 8 * NM_SMALL_TPA, 256, 256, unsigned char, true, true, 0, 32, true, true> CfgSmallQ8; // grids of <= 32 replicas
+#endif
 typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 192, unsigned char, true, true, 0, 256, true, true> CfgSmall;     // N <= 256: everything incl. the byte lists in LDS
 // element Al: Sutton-Chen EAM, 4^3 cells only (BASELINE config 4); 200 neighbour slots (134 within rc+skin in the crystal)
 typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 256, unsigned char, true, true, 1> CfgSmallSC;

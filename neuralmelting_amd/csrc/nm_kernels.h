@@ -18,6 +18,9 @@ namespace nm {
 #ifndef NM_AB
 #define NM_AB 0 // A/B experiments: a variant library is built with -DNM_AB=k (scripts/ab_multi.sh), the shipped one with 0
 #endif
+#ifndef NM_POLL_SLEEP
+#define NM_POLL_SLEEP 1 // s_sleep units (64 clocks each) between two polls of a hand-over granule (0: none)
+#endif
 #ifndef NM_PAIR_W
 #define NM_PAIR_W 2 // listed neighbours a thread works on at once (pair_vec)
 #endif
@@ -141,12 +144,18 @@ struct Cfg {
     static constexpr size_t OFF_RHO = OFF_NBR + (LDS_LIST2 ? 2 : 1) * LIST_BYTES; // EAM densities
     static constexpr size_t OFF_X0S = OFF_RHO + (POT ? (size_t)NMAX * sizeof(double) : 0); // LDS_LIST2: reference positions of the saved list
     static constexpr size_t OFF_CNTS = OFF_X0S + (LDS_LIST2 ? A3 : 0);                     //            and its row lengths
-    static constexpr size_t LDS_NATURAL = OFF_CNTS + (LDS_LIST2 ? pad8((size_t)NMAX * sizeof(unsigned short)) : 0);
+    // PREFETCH: the gaussians of the NEXT move's `velocity create` are drawn while the closing exchange of the current move's
+    // energy sums is in flight (Replica::prefetch_gaussians) and wait here, 3 NMAX doubles
+    // (measured 1.4 % SLOWER on C2 and C4, round 3: the 400 instructions per thread delay the poll more than the flight time they fill,
+    //  and the kernel spills 75 instead of 52 VGPRs.  Kept behind NM_AB == 6 for the record; off in the shipped build.)
+    static constexpr bool PREFETCH = (NM_AB == 6) && NMAX_ <= 256;
+    static constexpr size_t OFF_GAUSS = OFF_CNTS + (LDS_LIST2 ? pad8((size_t)NMAX * sizeof(unsigned short)) : 0);
+    static constexpr size_t LDS_NATURAL = OFF_GAUSS + (PREFETCH ? A3 : 0);
     // One workgroup per CU, by construction: a cluster's census and the Q selection count on it (nm_probe_kernel asserts it), and
     // two workgroups of different replicas on one CU measured slower.  A configuration that would fit twice
     // into the CU's 160 KB asks for a little more than half of them.
-#if NM_AB == 4 // experiment: 8 workgroups per replica, two (of different replicas) per CU
-    static constexpr size_t LDS_BYTES = (TPA_ == 16 || LDS_NATURAL > (size_t)82 * 1024) ? LDS_NATURAL : (size_t)82 * 1024;
+#if NM_AB == 4 // experiment: 256-thread workgroups (-DNM_SMALL_BLOCK=256 -DNM_SMALL_TPA=1), 8 per replica, two (of different replicas) per CU
+    static constexpr size_t LDS_BYTES = (BLOCK_ == 256 || LDS_NATURAL > (size_t)82 * 1024) ? LDS_NATURAL : (size_t)82 * 1024;
 #else
     static constexpr size_t LDS_BYTES = LDS_NATURAL > (size_t)82 * 1024 ? LDS_NATURAL : (size_t)82 * 1024;
 #endif
@@ -182,9 +191,34 @@ struct Cfg {
 // live-range neighbours of everything the trajectory loop keeps, which the allocator then spilled into that loop.  All state it
 // touches is in LDS at constant offsets; scalars come and go by value.  Makes ONE block reduction (the caller flips its buffer
 // parity) and returns sum m |v|^2 of the velocities it leaves.
+// the gaussians of `velocity all create ... dist gaussian`, divided by sqrt(m): 2N work items over all threads — item w < N draws
+// (vx, vy) of atom w, item N + w draws vz — written to three arrays of NMAX doubles at byte offset `off` of the LDS block (the
+// velocities, or the prefetch area).  A function of its own (Philox, log, sin, cos: ~400 instructions), called from two places.
+template <class C>
+__device__ __attribute__((noinline)) void gaussian_fill(uint32_t tag, int N, int gslot, double mass, uint32_t seed, uint32_t step, int off)
+{
+    constexpr int BLOCK = C::BLOCK;
+    const int tid = threadIdx.x;
+    N = __builtin_amdgcn_readfirstlane(N); gslot = __builtin_amdgcn_readfirstlane(gslot); off = __builtin_amdgcn_readfirstlane(off);
+    tag = __builtin_amdgcn_readfirstlane(tag); seed = __builtin_amdgcn_readfirstlane(seed); step = __builtin_amdgcn_readfirstlane(step);
+    mass = uniform(mass);
+    double *const gx = (double *)(nm_lds + off), *const gy = gx + C::NMAX, *const gz = gy + C::NMAX;
+    const double twopi = 6.283185307179586476925286766559;
+    const double fac = 1.0 / sqrt(mass);
+    for (int w = tid; w < 2 * N; w += BLOCK) {
+        const int part = w >= N ? 1 : 0, i = w - part * N;
+        uint32_t o[4];
+        philox4x32_10((uint32_t)i, part ? S_VEL_B : S_VEL_A, tag, step, seed, (uint32_t)gslot, o);
+        const double u1 = u01(o[0], o[1]), u2 = u01(o[2], o[3]);
+        const double r = sqrt(-2.0 * log(1.0 - u1));
+        if (part) gz[i] = r * cos(twopi * u2) * fac;
+        else { gx[i] = r * cos(twopi * u2) * fac; gy[i] = r * sin(twopi * u2) * fac; }
+    }
+}
+
 template <class C>
 __device__ __attribute__((noinline)) double velocity_create(double t, uint32_t tag, double L, int N, int gslot, int parity, double mass,
-                                                         double mvv2e, double kB, uint32_t seed, uint32_t step, short *im_g)
+                                                         double mvv2e, double kB, uint32_t seed, uint32_t step, short *im_g, int prefetched)
 {
     constexpr int BLOCK = C::BLOCK, NW = C::NW;
     constexpr size_t A1 = (size_t)C::NMAX * sizeof(double);
@@ -203,17 +237,12 @@ __device__ __attribute__((noinline)) double velocity_create(double t, uint32_t t
     N = __builtin_amdgcn_readfirstlane(N); gslot = __builtin_amdgcn_readfirstlane(gslot); parity = __builtin_amdgcn_readfirstlane(parity);
     tag = __builtin_amdgcn_readfirstlane(tag); seed = __builtin_amdgcn_readfirstlane(seed); step = __builtin_amdgcn_readfirstlane(step);
     t = uniform(t); L = uniform(L); mass = uniform(mass); mvv2e = uniform(mvv2e); kB = uniform(kB);
-    const double twopi = 6.283185307179586476925286766559;
-    const double m = mass, fac = 1.0 / sqrt(m), mt = m * N;
-    for (int w = tid; w < 2 * N; w += BLOCK) {
-        const int part = w >= N ? 1 : 0, i = w - part * N;
-        uint32_t o[4];
-        philox4x32_10((uint32_t)i, part ? S_VEL_B : S_VEL_A, tag, step, seed, (uint32_t)gslot, o);
-        const double u1 = u01(o[0], o[1]), u2 = u01(o[2], o[3]);
-        const double r = sqrt(-2.0 * log(1.0 - u1));
-        if (part) vz[i] = r * cos(twopi * u2) * fac;
-        else { vx[i] = r * cos(twopi * u2) * fac; vy[i] = r * sin(twopi * u2) * fac; }
-    }
+    const double m = mass, mt = m * N;
+    prefetched = __builtin_amdgcn_readfirstlane(prefetched);
+    if (C::PREFETCH && prefetched) { // drawn while the previous move's energy sums were crossing the cluster (prefetch_gaussians)
+        const double *const g = (const double *)(nm_lds + C::OFF_GAUSS);
+        for (int i = tid; i < N; i += BLOCK) { vx[i] = g[i]; vy[i] = g[C::NMAX + i]; vz[i] = g[2 * C::NMAX + i]; }
+    } else gaussian_fill<C>(tag, N, gslot, mass, seed, step, (int)C::OFF_VEL);
     __syncthreads();
     double a[16];
 #pragma unroll
@@ -662,10 +691,17 @@ struct Replica {
         for (int i = tid; i < N; i += BLOCK) {
             const int is = C::LIST_LDS ? i + (i >> 5) : i;
             // (v_fract_f64 first: a trajectory that is about to be rejected for an astronomic energy — the reference's never-undone
-            //  iterative trials produce overlapping atoms — may carry coordinates far beyond the integer range)
-            const unsigned int ux = (unsigned int)__double2int_rn(__builtin_amdgcn_fract(px[i] * invLd) * 65536.0) & 0xFFFFu,
-                               uy = (unsigned int)__double2int_rn(__builtin_amdgcn_fract(py[i] * invLd) * 65536.0) & 0xFFFFu,
-                               uz = (unsigned int)__double2int_rn(__builtin_amdgcn_fract(pz[i] * invLd) * 65536.0) & 0xFFFFu;
+            //  iterative trials produce overlapping atoms — may carry coordinates far beyond the integer range.  Beyond 2^40 box edges, or
+            //  not a number at all, an atom gets a made-up place of its own: such a state is rejected whatever its list says (its kinetic
+            //  energy is not finite either), but NaNs must not all land on the origin and overflow one another's rows — the fp32 test of
+            //  round 2 simply never matched them.)
+            const double sx = px[i] * invLd, sy = py[i] * invLd, sz_ = pz[i] * invLd;
+            unsigned int ux = (unsigned int)__double2int_rn(__builtin_amdgcn_fract(sx) * 65536.0) & 0xFFFFu,
+                         uy = (unsigned int)__double2int_rn(__builtin_amdgcn_fract(sy) * 65536.0) & 0xFFFFu,
+                         uz = (unsigned int)__double2int_rn(__builtin_amdgcn_fract(sz_) * 65536.0) & 0xFFFFu;
+            if (!(fabs(sx) < 1.0e12 && fabs(sy) < 1.0e12 && fabs(sz_) < 1.0e12)) {
+                ux = ((unsigned int)i * 0x9E37u) & 0xFFFFu; uy = ((unsigned int)i * 0x85EBu + 0x1234u) & 0xFFFFu; uz = ((unsigned int)i * 0xC2B3u + 0x5678u) & 0xFFFFu;
+            }
             cf[is] = (unsigned long long)(ux | (uy << 16)) | ((unsigned long long)uz << 32);
         }
         set_fresh(false); // the forces are gone
@@ -1106,6 +1142,9 @@ struct Replica {
                 poisoned |= po;
                 return true;
             }
+#if NM_POLL_SLEEP > 0
+            __builtin_amdgcn_s_sleep(NM_POLL_SLEEP); // a failed poll is not repeated at once: fewer loads in the way of the peers' stores
+#endif
             if ((++spins & 63) == 0) {
                 const unsigned long long now = wall_clock64();
                 if (t0 == 0) t0 = now | 1ull;
@@ -1161,6 +1200,44 @@ struct Replica {
         if (fl & 2) status |= ST_LIST_OVERFLOW; // a peer's list overflowed
 #pragma unroll
         for (int k = 0; k < K; ++k) s[k] = uniform(t[k]);
+    }
+
+    // the same in two halves, for work that can be done while the granules are in flight
+    __device__ __forceinline__ void exchange_put(const double (&s)[4])
+    {
+        double *xg = xb + (size_t)(gen & 1) * C::XBUF_DOUBLES;
+        if (tid < 4) {
+            double mine = s[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) mine = (tid == k) ? s[k] : mine;
+            put_granule(xg + 2 * (size_t)(C::XG_PART + 4 * q + tid), mine, my_magic());
+        }
+    }
+    __device__ __forceinline__ void exchange_get(double (&s)[4])
+    {
+        double *xg = xb + (size_t)(gen & 1) * C::XBUF_DOUBLES;
+        const unsigned long long mg = magic();
+        int timeout = 0, poisoned = 0;
+        const int lane = tid & 63;
+        double v[4] = { 0.0, 0.0, 0.0, 0.0 };
+        if (lane < Q) {
+            double *gs[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gs[k] = xg + 2 * (C::XG_PART + 4 * lane + k);
+            get_granules<4>(gs, mg, v, timeout, poisoned);
+        }
+        double t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            t[k] = 0.0;
+            for (int r = 0; r < Q; ++r) t[k] += __shfl(v[k], r, 64);
+        }
+        ++gen;
+        const int fl = block_any2<NW, NVMAX>(timeout != 0, poisoned != 0, red, parity);
+        if (fl & 1) status |= ST_SYNC_TIMEOUT;
+        if (fl & 2) status |= ST_LIST_OVERFLOW; // a peer's list overflowed
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = uniform(t[k]);
     }
 
     // a workgroup that leaves the block on its own finding (list overflow) marks everything its peers could be waiting for
@@ -1344,11 +1421,28 @@ struct Replica {
         st_eevals += 1.0; st_pairs += 0.5 * psum[2];
         if (!(U == U) || isinf(U)) status |= ST_NONFINITE;
     }
-    // completes an energy evaluation; `extra` is one more per-workgroup partial sum that rides along
-    __device__ double finish_sums(double extra)
+    // completes an energy evaluation; `extra` is one more per-workgroup partial sum that rides along.  next_m >= 0: the move that
+    // follows is move next_m of the block; if it is going to be a Hamiltonian move its gaussians are drawn between the publication of
+    // this workgroup's partial sums and the poll for the peers' — the ~1 us the sums need to cross the cluster otherwise passes idle.
+    // Philox is counter-based, so the values are those velocity_create would draw: results do not change by a bit.
+    int gauss_for = -1; // move index whose gaussians wait in the prefetch area
+    __device__ double finish_sums(double extra, int next_m = -1)
     {
         double s[4] = { psum[0], psum[1], psum[2], extra };
-        exchange_sums<4>(s);
+#if NM_AB == 5
+        next_m = -1;
+#endif
+        if (C::PREFETCH && Q > 1 && next_m >= 0 && next_m < p.mod && tape == nullptr && !p.md_mode) {
+            exchange_put(s);
+            uint32_t o[4];
+            philox4x32_10(0u, S_ROLL, (uint32_t)next_m, p.step, p.seed, (uint32_t)gslot, o);
+            const double roll = u01(o[0], o[1]); // (draw_scalar(S_ROLL, next_m, 0): block-uniform)
+            if (roll > p.ppos + p.pvol) {
+                gaussian_fill<C>((uint32_t)next_m, N, gslot, p.mass, p.seed, p.step, (int)C::OFF_GAUSS);
+                gauss_for = next_m; // (visible to every thread after exchange_get's barrier)
+            }
+            exchange_get(s);
+        } else exchange_sums<4>(s);
         psum[0] = s[0]; psum[1] = s[1]; psum[2] = s[2];
         take_sums();
         return s[3];
@@ -1368,11 +1462,11 @@ struct Replica {
     //   I about the COM            = raw second moments - M (|Xc|^2 1 - Xc Xc^T)   (parallel axis)
     // and one pass that writes v = sc (v - c) - omega x (X - Xc).  The second "zero linear" would subtract the round-off of
     // sum m v' / M (~1e-17 relative); it is left out.  Differences to the four-pass arithmetic are ~1e-15 relative.
-    __device__ __forceinline__ double hmc_velocities(double t, uint32_t tag)
+    __device__ __forceinline__ double hmc_velocities(double t, uint32_t tag, int prefetched)
     {
         short *img = nullptr;
         if constexpr (!C::SAVE_LDS) img = im.g;
-        const double mv2 = velocity_create<C>(t, tag, L, N, gslot, parity, p.mass, p.mvv2e, p.kB, p.seed, p.step, img);
+        const double mv2 = velocity_create<C>(t, tag, L, N, gslot, parity, p.mass, p.mvv2e, p.kB, p.seed, p.step, img, prefetched);
         parity ^= 1;
         // thread tid wrote atoms tid, tid + BLOCK, ...; in a cluster the readers that follow (save, the first half kick) take
         // the own atoms a0 + tid, ... — other threads' writes unless a0 == 0
@@ -1915,8 +2009,13 @@ enum : int { PH_INIT = 0, PH_BULK = 1, PH_VMC = 2, PH_HMC_START = 3, PH_HMC_STEP
 // evaluation; PH_ITER_END: the evaluation that closes an iterative position move of the EAM (its virial is not carried through the trials)
 
 // one workgroup = one replica for MOD moves
+#if NM_AB == 4
+#define NM_MIN_WAVES , 2 // (256-thread workgroups: without it the compiler takes the 512 registers a lone wave per SIMD may have)
+#else
+#define NM_MIN_WAVES
+#endif
 template <class C>
-__global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
+__global__ void __launch_bounds__(C::BLOCK NM_MIN_WAVES) nm_block_kernel(const KParams p)
 {
     constexpr int BLOCK = C::BLOCK;
     const unsigned long long t_entry = wall_clock64(); // (stats column 4)
@@ -1989,7 +2088,8 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
             R.eval(have_need, pre_need, phase == PH_HMC_STEP, c_dtfm);
             // cluster-wide U, W of an energy evaluation — ONE exchange site; the kinetic energy rides along.
             if (!(st_before & fatal) && !(R.status & (ST_BOX_TOO_SMALL | ST_SYNC_TIMEOUT)))
-                mv2new = R.finish_sums(phase == PH_HMC_STEP ? R.psum[3] : 0.0);
+                mv2new = R.finish_sums(phase == PH_HMC_STEP ? R.psum[3] : 0.0,
+                                       phase == PH_HMC_START || p.eval_only ? -1 : phase == PH_INIT ? m : m + 1); // the move that follows this evaluation
         }
         skip_eval = false;
         have_need = false;
@@ -2140,7 +2240,7 @@ __global__ void __launch_bounds__(C::BLOCK) nm_block_kernel(const KParams p)
             } else { // hamiltonian_mc, remcmc:598-608
                 if (!p.md_mode) nth += 1.0;
                 const uint32_t tag = R.draw_tag((uint32_t)m);
-                mv2_0 = R.hmc_velocities(q6(t), tag);
+                mv2_0 = R.hmc_velocities(q6(t), tag, R.gauss_for == m ? 1 : 0);
                 c_h = uniform(q6(dt)); // timestep %f
                 c_dtfm = 0.5 * c_h * p.ftm2v / p.mass;
                 R.wrap(); // run 0
