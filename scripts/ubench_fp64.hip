@@ -49,6 +49,46 @@ __global__ void k(double *out, unsigned long long *cyc, double a, double b)
 #define S(i) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(*(float *)&v##i) : "v"(v##i));
             OPS8(S)
 #undef S
+        } else if (K == 10) {
+#define S(i) asm volatile("v_fract_f64 %0, %0" : "+v"(v##i));
+            OPS8(S)
+#undef S
+        } else if (K == 11) {
+#define S(i) asm volatile("v_cndmask_b32 %0, 0, %0, vcc" : "+v"(*(int *)&v##i) : : );
+            OPS8(S)
+#undef S
+        } else if (K == 12) {
+#define S(i) asm volatile("v_fma_f64 %0, %0, %1, %1 clamp" : "+v"(v##i) : "v"(b));
+            OPS8(S)
+#undef S
+        } else if (K == 13) {
+#define S(i) asm volatile("v_max_f64 %0, %0, %1" : "+v"(v##i) : "v"(b));
+            OPS8(S)
+#undef S
+        } else if (K == 14) {
+#define S(i) asm volatile("v_cmp_lt_f64 vcc, %1, %2\n\tv_cndmask_b32 %0, 0, %0, vcc" : "+v"(*(int *)&v##i) : "v"(v##i), "v"(b) : "vcc");
+            OPS8(S)
+#undef S
+        } else if (K == 15) {
+#define S(i) asm volatile("v_ldexp_f64 %0, %0, 1" : "+v"(v##i));
+            OPS8(S)
+#undef S
+        } else if (K == 16) {
+#define S(i) asm volatile("v_rcp_f32 %0, %0" : "+v"(*(float *)&v##i));
+            OPS8(S)
+#undef S
+        } else if (K == 17) {
+#define S(i) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(v##i) : "v"(*(float *)&v##i));
+            OPS8(S)
+#undef S
+        } else if (K == 18) {
+#define S(i) asm volatile("v_mov_b32 %0, %1" : "=v"(*(int *)&v##i) : "v"(*(int *)&v##i));
+            OPS8(S)
+#undef S
+        } else if (K == 19) {
+#define S(i) asm volatile("v_lshl_add_u32 %0, %0, 3, %0" : "+v"(*(int *)&v##i));
+            OPS8(S)
+#undef S
         }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -69,9 +109,11 @@ void run(const char *name, int threads)
 }
 int main()
 {
-    for (int th : {64, 256, 512, 1024}) {
+    for (int th : {64, 512}) {
         run<0>("v_fma_f64", th); run<1>("v_add_f64", th); run<2>("v_mul_f64", th); run<3>("v_rndne_f64", th); run<7>("v_floor_f64", th);
         run<4>("v_rcp_f64", th); run<8>("v_rsq_f64", th); run<5>("v_cmp_lt_f64", th); run<6>("v_fma_f32", th); run<9>("v_cvt_f32_f64", th);
+        run<10>("v_fract_f64", th); run<11>("v_cndmask_b32", th); run<12>("v_fma_f64 clamp", th); run<13>("v_max_f64", th); run<14>("v_cmp_lt_f64 + v_cndmask_b32", th);
+        run<15>("v_ldexp_f64", th); run<16>("v_rcp_f32", th); run<17>("v_cvt_f64_f32", th); run<18>("v_mov_b32", th); run<19>("v_lshl_add_u32", th);
         printf("\n");
     }
     return 0;
