@@ -74,7 +74,9 @@ struct nm_ctx {
     // device
     double *d_x, *d_v, *d_box, *d_steps, *d_therm, *d_count, *d_et, *d_pf, *d_tq, *d_stats;
     float *d_ratio;
-    int *d_slot2buf, *d_status, *d_status_acc, *d_halt, *d_rerun, *d_nswaps;
+    int *d_slot2buf, *d_status, *d_status_acc, *d_halt, *d_rerun, *d_nswaps, *d_order;
+    unsigned long long *d_last_ticks;
+    bool use_order; // one workgroup per replica and more replicas than CUs: launch the slowest slots first (nm_order_kernel)
     unsigned int *d_census; // residency census of cluster launches (nm_kernels.h)
     // Calls queued on the stream since the host last looked at the outcome (settle): if a block of them stopped because its
     // cluster grid was not resident or a hand-over timed out, nothing after it has run (KParams::halt) and the same calls are
@@ -160,6 +162,7 @@ void fill_params(const nm_ctx *c, KParams &p)
         if (std::sscanf(e, "%d,%d", &n, &q) >= 1) { p.inj_rebuild = n; p.inj_q = q; }
     }
     p.status_acc = c->d_status_acc; p.halt = c->d_halt; p.rerun_mask = nullptr; p.inj_census = 0;
+    p.order = (c->use_order && c->cus == 1) ? c->d_order : nullptr; p.last_ticks = c->d_last_ticks;
 }
 
 // workgroups of a launch: 8 Q ceil(nslots / 8), the block kernel's cluster mapping (nm_kernels.h); nslots x Q when 8 divides nslots or Q = 1
@@ -168,6 +171,11 @@ unsigned int nm_grid(int nslots, int q) { return q == 1 ? (unsigned int)nslots :
 template <class C>
 hipError_t launch_block(const nm_ctx *c, const KParams &p)
 {
+    if (p.order) { // longest first, by what each slot's previous block took
+        hipLaunchKernelGGL(nm_order_kernel, dim3((c->nslots + 255) / 256), dim3(256), 0, c->stream, c->nslots, c->d_last_ticks, c->d_order);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     if (p.census) { // the arrival counter of this launch's residency census
         const hipError_t e = hipMemsetAsync(c->d_census, 0, sizeof(unsigned int), c->stream);
         if (e != hipSuccess) return e;
@@ -547,7 +555,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     CHK(hipSetDevice(cfg->device));
     CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->cus = 1; c->d_xbuf = nullptr; c->d_aux = nullptr; c->launch_id = 0; c->d_census = nullptr;
-    c->d_status_acc = nullptr; c->d_halt = nullptr; c->d_rerun = nullptr;
+    c->d_status_acc = nullptr; c->d_halt = nullptr; c->d_rerun = nullptr; c->d_order = nullptr; c->d_last_ticks = nullptr; c->use_order = false;
     std::string note;
     {
         int want = 8;
@@ -558,6 +566,9 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
         CHK(dalloc(&c->d_status_acc, (size_t)c->nslots));
         CHK(hipMemset(c->d_status_acc, 0, sizeof(int) * c->nslots));
         CHK(dalloc(&c->d_rerun, (size_t)c->nslots));
+        CHK(dalloc(&c->d_order, (size_t)c->nslots));
+        CHK(dalloc(&c->d_last_ticks, (size_t)c->nslots));
+        CHK(hipMemset(c->d_last_ticks, 0, sizeof(unsigned long long) * c->nslots)); // (first launch: all ties, i.e. index order)
         CHK(dalloc(&c->d_halt, 1));
         CHK(hipMemset(c->d_halt, 0, sizeof(int)));
         CHK(dalloc(&c->d_slot2buf, (size_t)c->nslots));
@@ -568,6 +579,12 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
         }
         if (pick_q(c, want, note) != NM_OK) { g_create_error = c->err; delete c; return NM_ERR_HIP; } // (workgroups per replica: see pick_q)
         if (!note.empty()) note = "nm_create: " + note;
+        {
+            hipDeviceProp_t prop;
+            CHK(hipGetDeviceProperties(&prop, cfg->device));
+            c->use_order = c->nslots > prop.multiProcessorCount; // (only matters while the context runs one workgroup per replica)
+            if (const char *e = std::getenv("NM_LAUNCH_ORDER")) c->use_order = std::atoi(e) != 0;
+        }
     }
     const size_t ns = c->nslots, n3 = (size_t)3 * c->N;
     CHK(dalloc(&c->d_x, ns * n3)); CHK(dalloc(&c->d_v, ns * n3));
@@ -635,7 +652,7 @@ int nm_destroy(nm_ctx *c)
     void *ptrs[] = { c->d_x, c->d_v, c->d_box, c->d_steps, c->d_therm, c->d_count, c->d_ratio, c->d_et, c->d_pf, c->d_tq,
                      c->d_stats, c->d_slot2buf, c->d_status, c->d_nswaps, c->d_evalU, c->d_evalW, c->d_evalF, c->d_xcrit,
                      c->d_xtape, c->d_tape, c->d_tape_off, c->d_trace, c->d_nbr, c->d_aux, c->d_prof, c->d_tline, c->d_xbuf, c->d_census,
-                     c->d_status_acc, c->d_halt, c->d_rerun };
+                     c->d_status_acc, c->d_halt, c->d_rerun, c->d_order, c->d_last_ticks };
     for (void *q : ptrs) if (q) hipFree(q);
     if (c->h_stage) hipHostFree(c->h_stage);
     hipStreamDestroy(c->stream);

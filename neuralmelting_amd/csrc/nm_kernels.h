@@ -2024,7 +2024,8 @@ __global__ void __launch_bounds__(C::BLOCK NM_MIN_WAVES) nm_block_kernel(const K
     // when 8 does not divide nslots the workgroups of the slots that do not exist only take the census and leave.  (Round 2 mapped
     // such grids slot = b / Q, which spread every cluster over all XCDs: write-through hand-overs, ~0.5 us more per hop.)
     const int Q = p.cus, b = blockIdx.x;
-    const int r_ = b >> 3, slot = (b & 7) + 8 * (r_ / Q), qq = r_ % Q;
+    const int r_ = b >> 3, qq = r_ % Q;
+    const int slot = (Q == 1 && p.order) ? p.order[b] : (b & 7) + 8 * (r_ / Q); // (Q = 1: the formula is the identity; order: longest first)
     if (halted(p)) return; // an earlier block stopped on an error: nothing runs on its state until the host has dealt with it
     if (slot >= p.nslots) { // padding workgroup
         if (Q > 1 && p.census) (void)residency_census<C>(p);
@@ -2301,10 +2302,30 @@ __global__ void __launch_bounds__(C::BLOCK NM_MIN_WAVES) nm_block_kernel(const K
         report_status(p, slot, R.status, false);
         double *st = p.stats + NM_STATS_COLS * (size_t)slot;
         st[0] += R.st_evals; st[1] += R.st_rebuilds; st[2] += R.st_eevals; st[3] += R.st_pairs;
-        st[4] += (double)(wall_clock64() - t_entry); st[5] += R.same_xcd ? 1.0 : 0.0; st[6] += 1.0; st[7] += nth - nth_entry; st[9] = (double)C::MAXNB;
+        const unsigned long long ticks = wall_clock64() - t_entry;
+        if (p.last_ticks) p.last_ticks[slot] = ticks;
+        st[4] += (double)ticks; st[5] += R.same_xcd ? 1.0 : 0.0; st[6] += 1.0; st[7] += nth - nth_entry; st[9] = (double)C::MAXNB;
 #ifdef NM_PROF
         if (p.prof) for (int q = 0; q < NM_PROF_SLOTS; ++q) p.prof[(size_t)slot * NM_PROF_SLOTS + q] += R.prof_acc[q];
 #endif
+    }
+}
+
+// Launch order for grids with more one-workgroup replicas than the chip holds at once (the reference's run.sh setting: 1024 replicas
+// on 256 CUs): workgroups are dispatched in index order, and a launch ends with whatever the last wave of workgroups happens to hold.
+// Longest-processing-time-first by the duration of each slot's PREVIOUS block (a slot's cost changes slowly: it is set by its pressure
+// and temperature) shortens the tail: order[rank] = slot, rank by descending ticks, ties by index.  Scheduling only: results do not
+// depend on it.
+__global__ void nm_order_kernel(int nslots, const unsigned long long *ticks, int *order)
+{
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nslots; k += gridDim.x * blockDim.x) {
+        const unsigned long long t = ticks[k];
+        int rank = 0;
+        for (int j = 0; j < nslots; ++j) {
+            const unsigned long long u = ticks[j];
+            rank += (u > t || (u == t && j < k)) ? 1 : 0;
+        }
+        order[rank] = k;
     }
 }
 

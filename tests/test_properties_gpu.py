@@ -374,3 +374,34 @@ def test_long_run_statistics_agree_with_the_oracle(oracle):
     ratio = g[-1, :, 5:8] / o[-1, :, 5:8]
     assert (ratio > 1 / 2.0).all() and (ratio < 2.0).all()
     assert abs(np.log(ratio).mean()) < 0.15
+
+
+def test_launch_order_changes_nothing_but_the_schedule(monkeypatch):
+    """More one-workgroup replicas than the chip has CUs (320 x 500 atoms, the kind of the reference's run.sh setting): from the second
+    block on the workgroups are issued slowest-slot-first (nm_order_kernel, by the duration of each slot's previous block).  That is
+    scheduling only: thermo rows, exchange permutations and configurations equal, bit for bit, those of the index-order launch."""
+    import neuralmelting_amd as nm
+    from neuralmelting_amd import lattice
+    P = np.linspace(1.0, 8.0, 16, dtype=np.float32)
+    T = np.linspace(0.25, 2.5, 20, dtype=np.float32)
+    x, v, box, d = lattice.init_states(5, P, T, 0.03125, 0.03125)
+    outs = []
+    for order in ('0', '1'):
+        monkeypatch.setenv('NM_LAUNCH_ORDER', order)
+        e = nm.Engine(500, P, T)
+        assert e.cus_per_replica == 1 and e.nslots == 320
+        e.set_state(x, v, box, d)
+        rows, perms = [], []
+        for step in range(3):
+            e.set_step(step)
+            e.run_block(12)
+            rows.append(e.thermo())
+            e.adapt()
+            e.exchange()
+            perms.append(e.perm())
+        outs.append((np.array(rows), np.array(perms), e.get_state()))
+        e.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    for a, b in zip(outs[0][2], outs[1][2]):
+        np.testing.assert_array_equal(a, b)
