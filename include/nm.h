@@ -70,7 +70,7 @@ typedef struct nm_config {
 /* life cycle */
 int nm_create(const nm_config *cfg, nm_ctx **out);
 int nm_destroy(nm_ctx *ctx);
-const char *nm_last_error(const nm_ctx *ctx);  /* ctx may be NULL: error of the last failed nm_create; empty after a call that returned NM_OK */
+const char *nm_last_error(const nm_ctx *ctx);  /* ctx may be NULL: error of the last failed nm_create; cleared by the next synchronising call that returns NM_OK */
 const char *nm_create_note(const nm_ctx *ctx); /* not an error: what the residency probe of nm_create gave up (fewer workgroups per replica
                                                   than asked for), and every block that was re-issued at a lower number later on        */
 int nm_nslots(const nm_ctx *ctx);              /* nrows*nt replicas held by this context               */

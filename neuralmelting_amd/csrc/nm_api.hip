@@ -349,7 +349,10 @@ int pick_q(nm_ctx *c, int qmax, std::string &note)
     int cu = prop.multiProcessorCount;
     if (testing())
         if (const char *e = std::getenv("NM_ASSUME_CUS")) { const int v = std::atoi(e); if (v > 0) cu = v; } // tests of the fallback
-    const int maxq = c->kind == 0 ? (c->pot == 0 ? 8 : 4) : c->kind == 1 ? 8 : 2; // own-atom ranges the instantiated thread mappings cover
+    int maxq = c->kind == 0 ? (c->pot == 0 ? 8 : 4) : c->kind == 1 ? 8 : 2; // own-atom ranges the instantiated thread mappings cover
+#if NM_AB == 9
+    if (c->kind == 2) maxq = 4; // experiment: 4 workgroups per 2048-atom replica
+#endif
     c->cus = 1;
     for (int qq : { 8, 4, 2 }) {
         if (qq > maxq || qq > qmax) continue;
@@ -407,7 +410,7 @@ int settle(nm_ctx *c)
         HIPCHK(c, hipMemcpy(st.data(), c->d_status_acc, sizeof(int) * c->nslots, hipMemcpyDeviceToHost));
         int any = 0;
         for (int v : st) any |= v;
-        if (!halt && !any) { c->journal.clear(); return NM_OK; }
+        if (!halt && !any) { c->journal.clear(); c->err.clear(); return NM_OK; } // (nm_last_error is empty after a call that returned NM_OK)
         const int healable = ST_NOT_RESIDENT | ST_SYNC_TIMEOUT;
         size_t at = c->journal.size();
         for (size_t k = 0; k < c->journal.size(); ++k)
