@@ -12,6 +12,7 @@
 //   Replica::advance_and_share, exchange_sums (no counterpart)  hand-over between the workgroups that share one replica
 #pragma once
 #include "nm_device.h"
+#include "nm_math.h"
 
 namespace nm {
 
@@ -210,9 +211,11 @@ __device__ __attribute__((noinline)) void gaussian_fill(uint32_t tag, int N, int
         uint32_t o[4];
         philox4x32_10((uint32_t)i, part ? S_VEL_B : S_VEL_A, tag, step, seed, (uint32_t)gslot, o);
         const double u1 = u01(o[0], o[1]), u2 = u01(o[2], o[3]);
-        const double r = sqrt(-2.0 * log(1.0 - u1));
-        if (part) gz[i] = r * cos(twopi * u2) * fac;
-        else { gx[i] = r * cos(twopi * u2) * fac; gy[i] = r * sin(twopi * u2) * fac; }
+        const double r = sqrt(-2.0 * log_pos(1.0 - u1)); // (nm_math.h: the same functions of the same arguments, within 1 ulp like the library's)
+        double sn, cs;
+        sincos_2pi(twopi * u2, sn, cs);
+        if (part) gz[i] = r * cs * fac;
+        else { gx[i] = r * cs * fac; gy[i] = r * sn * fac; }
     }
 }
 
@@ -268,8 +271,9 @@ __device__ __attribute__((noinline)) double velocity_create(double t, uint32_t t
 #else
     block_sum<16, NW, NVMAX>(a, red, parity, min(NW, (N + 63) >> 6)); // (atoms are dealt out by thread index: N <= 256 leaves half the waves empty)
 #endif
-    const double c0 = a[0] / mt, c1 = a[1] / mt, c2 = a[2] / mt;   // COM velocity
-    const double cx = a[3] / mt, cy = a[4] / mt, cz = a[5] / mt;   // centre of mass (unwrapped)
+    const double imt = 1.0 / mt; // (one division instead of six, and one for the inertia tensor below instead of three: every thread does all of this)
+    const double c0 = a[0] * imt, c1 = a[1] * imt, c2 = a[2] * imt;   // COM velocity
+    const double cx = a[3] * imt, cy = a[4] * imt, cz = a[5] * imt;   // centre of mass (unwrapped)
     const double dof = 3.0 * N - 3.0;
     const double s2 = a[6] - mt * (c0 * c0 + c1 * c1 + c2 * c2);
     const double tcur = s2 * mvv2e / (dof * kB);
@@ -285,9 +289,10 @@ __device__ __attribute__((noinline)) double velocity_create(double t, uint32_t t
         const double i00 = I11 * I22 - I12 * I12, i01 = -(I01 * I22 - I02 * I12), i02 = I01 * I12 - I02 * I11;
         const double i10 = -(I01 * I22 - I12 * I02), i11 = I00 * I22 - I02 * I02, i12 = -(I00 * I12 - I02 * I01);
         const double i20 = I01 * I12 - I11 * I02, i21 = -(I00 * I12 - I01 * I02), i22 = I00 * I11 - I01 * I01;
-        w0 = (i00 * L0_ + i01 * L1_ + i02 * L2_) / det;
-        w1 = (i10 * L0_ + i11 * L1_ + i12 * L2_) / det;
-        w2 = (i20 * L0_ + i21 * L1_ + i22 * L2_) / det;
+        const double idet = 1.0 / det;
+        w0 = (i00 * L0_ + i01 * L1_ + i02 * L2_) * idet;
+        w1 = (i10 * L0_ + i11 * L1_ + i12 * L2_) * idet;
+        w2 = (i20 * L0_ + i21 * L1_ + i22 * L2_) * idet;
     }
     for (int i = tid; i < N; i += BLOCK) {
         const double dx = px[i] + im[3 * i] * L - cx, dy = py[i] + im[3 * i + 1] * L - cy, dz = pz[i] + im[3 * i + 2] * L - cz;
