@@ -77,7 +77,8 @@ struct nm_ctx {
     int *d_slot2buf, *d_status, *d_status_acc, *d_halt, *d_rerun, *d_nswaps, *d_order;
     unsigned long long *d_last_ticks;
     bool use_order; // one workgroup per replica and more replicas than CUs: launch the slowest slots first (nm_order_kernel)
-    unsigned int *d_census; // residency census of cluster launches (nm_kernels.h)
+    unsigned int *d_census; // residency census of cluster launches (nm_kernels.h): the grid's counter, then one per cluster
+    bool over;              // the grid holds twice the clusters the chip does at once (pick_q)
     // Calls queued on the stream since the host last looked at the outcome (settle): if a block of them stopped because its
     // cluster grid was not resident or a hand-over timed out, nothing after it has run (KParams::halt) and the same calls are
     // issued again with fewer workgroups per replica.
@@ -149,7 +150,7 @@ void fill_params(const nm_ctx *c, KParams &p)
     p.nbr_g = c->d_nbr; p.aux_g = c->d_aux;
     p.prof = c->d_prof;
     p.cus = c->cus; p.xbuf = c->d_xbuf; p.launch_id = c->launch_id;
-    p.census = c->cus > 1 ? c->d_census : nullptr;
+    p.census = c->cus > 1 ? c->d_census : nullptr; p.over = (c->cus > 1 && c->over) ? 1 : 0;
     p.plain_granules = 1;
     if (const char *e = std::getenv("NM_PLAIN_GRANULES")) p.plain_granules = std::atoi(e);
     p.dbg = 0;
@@ -162,11 +163,12 @@ void fill_params(const nm_ctx *c, KParams &p)
         if (std::sscanf(e, "%d,%d", &n, &q) >= 1) { p.inj_rebuild = n; p.inj_q = q; }
     }
     p.status_acc = c->d_status_acc; p.halt = c->d_halt; p.rerun_mask = nullptr; p.inj_census = 0;
-    p.order = (c->use_order && c->cus == 1) ? c->d_order : nullptr; p.last_ticks = c->d_last_ticks;
+    p.order = (c->use_order && (c->cus == 1 || c->over)) ? c->d_order : nullptr; p.last_ticks = c->d_last_ticks;
 }
 
 // workgroups of a launch: 8 Q ceil(nslots / 8), the block kernel's cluster mapping (nm_kernels.h); nslots x Q when 8 divides nslots or Q = 1
 unsigned int nm_grid(int nslots, int q) { return q == 1 ? (unsigned int)nslots : (unsigned int)(8 * q * ((nslots + 7) / 8)); }
+size_t census_words(int nslots) { return 1 + (size_t)8 * ((nslots + 7) / 8); } // the grid's counter + one per cluster
 
 template <class C>
 hipError_t launch_block(const nm_ctx *c, const KParams &p)
@@ -176,8 +178,8 @@ hipError_t launch_block(const nm_ctx *c, const KParams &p)
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    if (p.census) { // the arrival counter of this launch's residency census
-        const hipError_t e = hipMemsetAsync(c->d_census, 0, sizeof(unsigned int), c->stream);
+    if (p.census) { // the arrival counters of this launch's residency census
+        const hipError_t e = hipMemsetAsync(c->d_census, 0, sizeof(unsigned int) * census_words(c->nslots), c->stream);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(nm_block_kernel<C>, dim3(nm_grid(c->nslots, c->cus)), dim3(C::BLOCK), C::LDS_BYTES, c->stream, p);
@@ -189,7 +191,7 @@ hipError_t launch_probe(const nm_ctx *c, const KParams &p)
 {
     hipError_t e = hipFuncSetAttribute((const void *)nm_probe_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(c->d_census, 0, sizeof(unsigned int), c->stream);
+    e = hipMemsetAsync(c->d_census, 0, sizeof(unsigned int) * census_words(c->nslots), c->stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(nm_probe_kernel<C>, dim3(nm_grid(c->nslots, c->cus)), dim3(C::BLOCK), C::LDS_BYTES, c->stream, p);
     return hipGetLastError();
@@ -349,16 +351,28 @@ int pick_q(nm_ctx *c, int qmax, std::string &note)
     int cu = prop.multiProcessorCount;
     if (testing())
         if (const char *e = std::getenv("NM_ASSUME_CUS")) { const int v = std::atoi(e); if (v > 0) cu = v; } // tests of the fallback
-    int maxq = c->kind == 0 ? (c->pot == 0 ? 8 : 4) : c->kind == 1 ? 8 : 2; // own-atom ranges the instantiated thread mappings cover
-#if NM_AB == 9
-    if (c->kind == 2) maxq = 4; // experiment: 4 workgroups per 2048-atom replica
-#endif
-    c->cus = 1;
+    const int maxq = c->kind == 0 ? (c->pot == 0 ? 8 : 4) : c->kind == 1 ? 8 : 4; // own-atom ranges the instantiated thread mappings cover
+    c->cus = 1; c->over = false;
+    // The large cells (N > 864) at 4 workgroups per replica when that makes a grid of (nearly) TWICE the chip: the clusters run in
+    // two rounds, longest block first, each with its own census.  Their blocks differ by more than 2x across an equilibrated PxT grid
+    // (31-73 ms at 8^3, two workgroups each), so a resident grid of two workgroups per replica lasts as long as its slowest member while
+    // a third of the CUs have nothing left to do; four workgroups make a block ~1.6x shorter, and two rounds of them, dealt out longest first,
+    // end within a few ms of one another.  Measured on C5's per-GPU share (128 x 2048 atoms): equilibrated chains 221 k sweeps/s against
+    // 211 k for the resident grid (+4.5 %: 74 ms per launch where perfect packing of the same blocks would give 67), but 276 k against
+    // 324 k while all replicas are still alike (nothing to even out, and 4 workgroups per replica cost 1.27x the CU time of 2).  So it
+    // is opt-in: NM_OVERSUBSCRIBE=1.  (It also leans on workgroups being dispatched in index order within an XCD, which HIP does not
+    // promise; a cluster whose members do not gather fails its census and the block is re-issued on the resident grid, settle().)
+    bool try_over = false;
+    if (const char *e = std::getenv("NM_OVERSUBSCRIBE")) try_over = c->kind == 2 && qmax >= 4 && std::atoi(e) != 0;
+    for (int pass = try_over ? 0 : 1; pass < 2; ++pass)
     for (int qq : { 8, 4, 2 }) {
         if (qq > maxq || qq > qmax) continue;
         const int per_cu = blocks_per_cu_kind(c->kind, c->pot, qq);
-        if ((long)nm_grid(c->nslots, qq) > (long)per_cu * cu) continue;
-        c->cus = qq; // probe: does the grid of this Q gather?
+        const long grid = (long)nm_grid(c->nslots, qq), room = (long)per_cu * cu;
+        const bool over = pass == 0;
+        if (over) { if (qq != 4 || grid > 2 * room || 4 * grid < 7 * room) continue; } // 1.75 .. 2 chips' worth of workgroups
+        else if (grid > room) continue;
+        c->cus = qq; c->over = over; // probe: does the grid of this Q gather?
         KParams p;
         fill_params(c, p);
         p.status_acc = nullptr; p.halt = nullptr;
@@ -374,7 +388,7 @@ int pick_q(nm_ctx *c, int qmax, std::string &note)
         char buf[200];
         std::snprintf(buf, sizeof buf, "%d workgroups per replica (%d in all) did not gather on this device; falling back. ", qq, (int)nm_grid(c->nslots, qq));
         note += buf;
-        c->cus = 1;
+        c->cus = 1; c->over = false;
     }
     return NM_OK;
 }
@@ -557,13 +571,13 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     } while (0)
     CHK(hipSetDevice(cfg->device));
     CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    c->cus = 1; c->d_xbuf = nullptr; c->d_aux = nullptr; c->launch_id = 0; c->d_census = nullptr;
+    c->cus = 1; c->d_xbuf = nullptr; c->d_aux = nullptr; c->launch_id = 0; c->d_census = nullptr; c->over = false;
     c->d_status_acc = nullptr; c->d_halt = nullptr; c->d_rerun = nullptr; c->d_order = nullptr; c->d_last_ticks = nullptr; c->use_order = false;
     std::string note;
     {
         int want = 8;
         if (const char *e = std::getenv("NM_CUS_PER_REPLICA")) want = std::atoi(e);
-        CHK(dalloc(&c->d_census, 1));
+        CHK(dalloc(&c->d_census, census_words(c->nslots)));
         CHK(dalloc(&c->d_status, (size_t)c->nslots));
         CHK(hipMemset(c->d_status, 0, sizeof(int) * c->nslots));
         CHK(dalloc(&c->d_status_acc, (size_t)c->nslots));
@@ -585,7 +599,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
         {
             hipDeviceProp_t prop;
             CHK(hipGetDeviceProperties(&prop, cfg->device));
-            c->use_order = c->nslots > prop.multiProcessorCount; // (only matters while the context runs one workgroup per replica)
+            c->use_order = c->over || c->nslots > prop.multiProcessorCount; // (more workgroups / clusters than the chip holds at once: longest first)
             if (const char *e = std::getenv("NM_LAUNCH_ORDER")) c->use_order = std::atoi(e) != 0;
         }
     }

@@ -57,6 +57,7 @@ struct KParams {
                                    // has dealt with it (nm_api.hip settle): a failed block never has successors running on its state
     const int *rerun_mask;         // re-issue of a block after a hand-over timeout: only the slots marked here run; null = all
     int inj_census;                // fault injection (NM_TESTING=1, NM_INJECT_CENSUS): this launch's residency census fails
+    int over;                      // the grid holds more clusters than the chip at once: every cluster takes its own census (census[1 + cluster])
     const int *order;              // one workgroup per replica and more replicas than the chip holds at once: workgroup b runs slot order[b],
                                    // slowest first (by the time each slot's previous block took); null = identity
     unsigned long long *last_ticks; // per slot: duration of its last block (100 MHz ticks), what nm_order_kernel sorts by

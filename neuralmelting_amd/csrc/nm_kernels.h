@@ -1985,24 +1985,31 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
 // whoever gives up sets an abort bit (by compare-and-swap on the short count it saw) that also fails every later arrival, so the
 // verdict is unanimous.  Returns false when the
 // grid did not gather; the caller has touched nothing by then.
+// A grid of more clusters than the chip holds at once (p.over: twice as many, launched longest block first — the replicas of an 8^3
+// grid take 31-73 ms per block at two workgroups each, so a resident grid idles a third of the time behind its slowest member)
+// cannot gather as a whole and need not: a cluster only waits for its own members, which the dispatcher places one after the other
+// (workgroups are handed to an XCD in index order: the next cluster's Q workgroups get the Q CUs that a finished cluster frees), so
+// there every cluster takes its own census on its own counter, with the same bound and the same unanimous verdict.
 template <class C>
-__device__ __forceinline__ bool residency_census(const KParams &p)
+__device__ __forceinline__ bool residency_census(const KParams &p, int cluster)
 {
     constexpr unsigned int ABORT = 0x80000000u;
     int *flag = (int *)(nm_lds + C::OFF_RED);
     if (threadIdx.x == 0) {
-        const unsigned int want = p.inj_census ? gridDim.x + 1u : gridDim.x; // (injection: a count nobody can complete)
-        atomicAdd(p.census, 1u);
+        unsigned int *const counter = p.over ? p.census + 1 + cluster : p.census;
+        const unsigned int full = p.over ? (unsigned int)p.cus : gridDim.x;
+        const unsigned int want = p.inj_census ? full + 1u : full; // (injection: a count nobody can complete)
+        atomicAdd(counter, 1u);
         const unsigned long long t0 = wall_clock64();
         int ok = 0;
         for (;;) {
-            const unsigned int v = __hip_atomic_load(p.census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int v = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (v == want) { ok = 1; break; }
             if (v & ABORT) break;
             if (wall_clock64() - t0 > 20000ull) { // 200 us of the 100 MHz clock: give up — but only on a count that is still short.
                 // compare-and-swap, not an unconditional OR: had the last workgroup signed in meanwhile, an abort bit set on top of the
                 // full count would fail the workgroups that have not looked yet while this one passes
-                if (atomicCAS(p.census, v, v | ABORT) == v) break;
+                if (atomicCAS(counter, v, v | ABORT) == v) break;
                 continue; // the counter moved: look again (a full count passes, somebody else's abort fails)
             }
             __builtin_amdgcn_s_sleep(4);
@@ -2025,7 +2032,8 @@ __global__ void __launch_bounds__(C::BLOCK) nm_probe_kernel(const KParams p)
 #endif
     const int Q = p.cus, b = blockIdx.x;
     const int slot = (b & 7) + 8 * ((b >> 3) / Q); // (the block kernel's mapping; a padding workgroup takes the census and leaves)
-    if (!residency_census<C>(p) && threadIdx.x == 0 && slot < p.nslots) atomicOr(&p.status[slot], (int)ST_NOT_RESIDENT);
+    if (p.over && slot >= p.nslots) return;        // (clusters that do not exist have no census of their own)
+    if (!residency_census<C>(p, slot) && threadIdx.x == 0 && slot < p.nslots) atomicOr(&p.status[slot], (int)ST_NOT_RESIDENT);
 }
 
 // Phases of the per-replica state machine.  The block kernel is written so that eval() — by far the largest
@@ -2051,10 +2059,11 @@ __global__ void __launch_bounds__(C::BLOCK NM_MIN_WAVES) nm_block_kernel(const K
     // such grids slot = b / Q, which spread every cluster over all XCDs: write-through hand-overs, ~0.5 us more per hop.)
     const int Q = p.cus, b = blockIdx.x;
     const int r_ = b >> 3, qq = r_ % Q;
-    const int slot = (Q == 1 && p.order) ? p.order[b] : (b & 7) + 8 * (r_ / Q); // (Q = 1: the formula is the identity; order: longest first)
+    const int cluster = (b & 7) + 8 * (r_ / Q);    // (Q = 1: b itself)
+    const int slot = (p.order && cluster < p.nslots) ? p.order[cluster] : cluster; // order: the replicas with the longest blocks first
     if (halted(p)) return; // an earlier block stopped on an error: nothing runs on its state until the host has dealt with it
     if (slot >= p.nslots) { // padding workgroup
-        if (Q > 1 && p.census) (void)residency_census<C>(p);
+        if (Q > 1 && p.census && !p.over) (void)residency_census<C>(p, cluster);
         return;
     }
     const int buf = p.slot2buf[slot];
@@ -2063,7 +2072,7 @@ __global__ void __launch_bounds__(C::BLOCK NM_MIN_WAVES) nm_block_kernel(const K
     const bool writer = (tid == 0 && qq == 0); // one workgroup of the cluster writes the replica's results
     const int N = p.N;
 
-    if (Q > 1 && p.census && !residency_census<C>(p)) { // nothing has been touched yet
+    if (Q > 1 && p.census && !residency_census<C>(p, cluster)) { // nothing has been touched yet
         if (writer) report_status(p, slot, ST_NOT_RESIDENT, true);
         return;
     }
@@ -2338,6 +2347,9 @@ __global__ void __launch_bounds__(C::BLOCK NM_MIN_WAVES) nm_block_kernel(const K
         const unsigned long long ticks = wall_clock64() - t_entry;
         if (p.last_ticks) p.last_ticks[slot] = ticks;
         st[4] += (double)ticks; st[5] += R.same_xcd ? 1.0 : 0.0; st[6] += 1.0; st[7] += nth - nth_entry; st[9] = (double)C::MAXNB;
+#if NM_AB == 8 // dev probe (scripts/probe_rounds.py): when did this slot's block start (100 MHz ticks)
+        st[9] = (double)t_entry;
+#endif
 #ifdef NM_PROF
         if (p.prof) for (int q = 0; q < NM_PROF_SLOTS; ++q) p.prof[(size_t)slot * NM_PROF_SLOTS + q] += R.prof_acc[q];
 #endif
@@ -2358,7 +2370,10 @@ __global__ void nm_order_kernel(int nslots, const unsigned long long *ticks, int
             const unsigned long long u = ticks[j];
             rank += (u > t || (u == t && j < k)) ? 1 : 0;
         }
-        order[rank] = k;
+        // Workgroup (cluster) c runs on XCD c % 8, whose CUs it cannot leave: dealt out 0..7, 0..7, ... the XCDs' shares of the sorted
+        // sequence would differ systematically (XCD 0 the longest of every eight); 0..7, 7..0, ... evens them out
+        const int g = rank >> 3, pos = rank & 7;
+        order[(g & 1) && 8 * g + 8 <= nslots ? 8 * g + 7 - pos : rank] = k;
     }
 }
 

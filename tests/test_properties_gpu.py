@@ -294,6 +294,57 @@ def test_a_launch_that_is_not_resident_is_reissued_with_fewer_workgroups(monkeyp
     np.testing.assert_array_equal(ra[:, :8], rc_[:, :8])
 
 
+def test_a_grid_of_twice_the_chip_heals_to_the_resident_one(monkeypatch):
+    """NM_OVERSUBSCRIBE=1: 128 replicas of 2048 atoms at 4 workgroups each run as two rounds of clusters, every cluster with its own
+    residency census.  A launch whose censuses fail (injected) leaves the replicas untouched; the library re-issues it on the resident
+    grid of 2 workgroups per replica, and the result is that of a context that ran there all along."""
+    import neuralmelting_amd as nm
+    from neuralmelting_amd import lattice
+    P = np.linspace(1.0, 8.0, 32, dtype=np.float32); T = np.linspace(0.25, 2.5, 32, dtype=np.float32)
+    x, v, box, d = lattice.init_states(8, P, T, 0.03125, 0.03125, row0=0, nrows=4)
+    mod = 4
+
+    def cycle(e, step):
+        e.set_step(step)
+        e.run_block(mod)
+        e.adapt()
+        e.exchange(count=False)
+
+    monkeypatch.setenv('NM_OVERSUBSCRIBE', '1')
+    monkeypatch.setenv('NM_INJECT_CENSUS', '1')
+    a = nm.Engine(2048, P, T, row0=0, nrows=4)
+    assert a.cus_per_replica == 4 and a.nslots == 128 and a.note() == ''
+    a.set_state(x, v, box, d)
+    for step in range(2):
+        cycle(a, step)
+    a.synchronize()                                            # notices, re-issues cycle 1 at Q = 2
+    monkeypatch.delenv('NM_INJECT_CENSUS')
+    assert a.cus_per_replica == 2
+    assert 'step 1 stopped at 4 workgroups per replica (grid not resident); re-issued at 2' in a.note()
+    assert (a.status() == 0).all()
+    ra, (xa, va, ba, da) = a.thermo(), a.get_state()
+    a.close()
+
+    b = nm.Engine(2048, P, T, row0=0, nrows=4)                 # cycle 0 on the oversubscribed grid
+    assert b.cus_per_replica == 4
+    b.set_state(x, v, box, d)
+    cycle(b, 0)
+    rb, (xb, vb, bb, db) = b.thermo(), b.get_state()
+    b.close()
+    monkeypatch.delenv('NM_OVERSUBSCRIBE')
+    c = nm.Engine(2048, P, T, row0=0, nrows=4)                 # cycle 1 on the resident one
+    assert c.cus_per_replica == 2
+    c.set_state(xb, vb, bb, db)
+    c.set_thermo(rb[:, :5])
+    cycle(c, 1)
+    rc_, (xc, vc, bc, dc) = c.thermo(), c.get_state()
+    c.close()
+    np.testing.assert_array_equal(xa, xc)
+    np.testing.assert_array_equal(va, vc)
+    np.testing.assert_array_equal(ba, bc)
+    np.testing.assert_array_equal(ra[:, :8], rc_[:, :8])
+
+
 def test_box_smaller_than_twice_the_cutoff_is_refused():
     nm, e = _dense_engine(8, 8, 4.9)
     with pytest.raises(nm.NMError) as err:

@@ -1,7 +1,8 @@
 """BASELINE configs at the size one GPU holds of them: C3's per-GPU share (LJ 6^3, 2 x 16 rows = 32 replicas of
 864 atoms, 8 workgroups per replica), C5's (LJ 8^3, 4 x 32 = 128 replicas of 2048 atoms, 2 workgroups per replica) and C4
 (Al EAM, 8 x 8 replicas of 256 atoms, 4 workgroups per replica).  All three fill the chip exactly (nslots x Q = 256 workgroups,
-the edge the cluster hand-over depends on).  One block against the oracle on a subset of the slots — the oracle needs seconds
+the edge the cluster hand-over depends on); C5's share also as a grid of TWICE the chip (NM_OVERSUBSCRIBE=1: 4 workgroups per replica,
+two rounds of clusters with a census each, longest block first).  One block against the oracle on a subset of the slots — the oracle needs seconds
 per slot at these sizes — and the invariants + bit-identical replay on all of them."""
 import numpy as np
 import pytest
@@ -16,8 +17,15 @@ RTOL = 1e-6
 SHARES = [
     ('C3', 'LJ', 6, 2, 16, 16, 8, 12, (0, 5, 15, 16, 26, 31)),
     ('C5', 'LJ', 8, 4, 32, 32, 2, 8, (0, 31, 45, 77, 100, 127)),
+    ('C5x2', 'LJ', 8, 4, 32, 32, 4, 8, (0, 31, 64, 127)),
     ('C4', 'Al', 4, 8, 8, 8, 4, 24, (0, 7, 9, 28, 36, 54, 63)),
 ]
+
+
+@pytest.fixture(autouse=True)
+def oversubscribe(request, monkeypatch):
+    if 'C5x2' in request.node.name:
+        monkeypatch.setenv('NM_OVERSUBSCRIBE', '1')
 
 
 def run_share(el, sz, nrows, np_all, nt, mod, cycles=1):
@@ -45,7 +53,7 @@ def run_share(el, sz, nrows, np_all, nt, mod, cycles=1):
 def test_share_one_block_against_the_oracle(oracle, name, el, sz, nrows, np_all, nt, q, mod, slots):
     r = run_share(el, sz, nrows, np_all, nt, mod)
     n = 4 * sz ** 3
-    assert r['ns'] == nrows * nt and r['q'] == q and r['ns'] * r['q'] == 256      # the whole chip, no CU to spare
+    assert r['ns'] == nrows * nt and r['q'] == q and r['ns'] * r['q'] == (512 if name == 'C5x2' else 256)  # the whole chip, no CU to spare (or twice)
     rows = r['rows'][0]
     et, pf, tq = (constants_lj if el == 'LJ' else constants_metal)(r['P'], r['T'], 0, nrows)
     kw = dict(units=1, mass=lattice.MASS['Al'], pot=1) if el == 'Al' else {}
