@@ -21,7 +21,7 @@ def main():
     total = 0
     P = np.linspace(1.0, 8.0, 2, dtype=np.float32)
     T = np.linspace(0.25, 2.5, 4, dtype=np.float32)
-    for sz, qs in ((5, (1, 2, 4, 8)), (6, (1, 2, 4, 8)), (8, (1, 2))):
+    for sz, qs in ((5, (1, 2, 4, 8)), (6, (1, 2, 4, 8)), (8, (1, 2, 4))):
         for q in qs:
             for bulk in (True, False):
                 os.environ['NM_CUS_PER_REPLICA'] = str(q)
