@@ -765,13 +765,18 @@ struct Replica {
                     const int jb = sub * CH + k0;
                     const int ntest = (min(32, CH - k0) + 7) & ~7; // (16 candidates per thread at 8 workgroups per replica: two groups of eight)
 #pragma unroll 1
-                    for (int b0 = 0; b0 < ntest; b0 += 8) // eight tests in flight
+                    for (int b0 = 0; b0 < ntest; b0 += 8) { // eight candidates in flight: all eight reads first, then the tests (written as
+                        // one loop the compiler put `s_waitcnt lgkmcnt(0)` behind every single read: 32 LDS latencies in a row per thread,
+                        // half of a rebuild)
+                        unsigned long long cj[8];
 #pragma unroll
-                        for (int b = b0; b < b0 + 8; ++b) {
-                            const int j = jb + b, js = j + (j >> 5); // (beyond the block or N: whatever lies there, masked below)
-                            const unsigned long long cj = cf[js];
-                            m = test16(m, xyi, zi, (unsigned int)cj, (unsigned int)(cj >> 32), t2);
+                        for (int u = 0; u < 8; ++u) {
+                            const int j = jb + b0 + u; // (beyond the block or N: whatever lies there, masked below)
+                            cj[u] = cf[j + (j >> 5)];
                         }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) m = test16(m, xyi, zi, (unsigned int)cj[u], (unsigned int)(cj[u] >> 32), t2);
+                    }
                     m = __brev(m) >> (32 - ntest); // test b sat in bit ntest - 1 - b
                     const int valid = min(32, min(CH - k0, N - jb)); // candidates of this round that exist
                     m &= valid >= 32 ? 0xFFFFFFFFu : valid > 0 ? (1u << valid) - 1u : 0u;
