@@ -1017,8 +1017,13 @@ struct Replica {
                     static_assert(PW % W == 0, "");
                     const unsigned long long *nb64 = (const unsigned long long *)nbr_cur();
                     const int mine = (c - sub + TPA - 1) / TPA; // neighbours of atom i that this thread handles: slots sub, sub+TPA, ...
+                    constexpr int KLAST = MAXNB / TPA - PW;     // first entry of a thread's last list word
+                    unsigned long long wn = nb64[(size_t)lrow(i) * TPA + sub];
                     for (int k0 = 0; k0 < mine; k0 += PW) {     // one conflict-free 8-byte read = PW of them
-                        const unsigned long long wd = nb64[((size_t)(k0 >> C::LOG2PW) * C::NLIST + lrow(i)) * TPA + sub];
+                        const unsigned long long wd = wn;
+                        // the NEXT word is asked for now and looked at PW entries later (unconditionally: clamped to the row's last word) —
+                        // read where it is needed, its LDS latency stood in front of every PW-th pair evaluation
+                        wn = nb64[((size_t)(min(k0 + PW, KLAST) >> C::LOG2PW) * C::NLIST + lrow(i)) * TPA + sub];
 #pragma unroll
                         for (int e0 = 0; e0 < PW; e0 += W) {
                             if (k0 + e0 == NM_PRIO_SW) prio_swap();
