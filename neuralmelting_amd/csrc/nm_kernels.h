@@ -1822,8 +1822,10 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
             const double xi = __builtin_fma(px[i], invL, 0.5), yi = __builtin_fma(py[i], invL, 0.5), zi = __builtin_fma(pz[i], invL, 0.5); // (minimum image as in pair_pre)
             const int c = cnt[i];
             const int mine = (c - sub + TPA - 1) / TPA;
+            unsigned long long wn = nb64[(size_t)lrow(i) * TPA + sub];
             for (int k0 = 0; k0 < mine; k0 += 8) {
-                const unsigned long long wd = nb64[((size_t)(k0 >> 3) * C::NLIST + lrow(i)) * TPA + sub];
+                const unsigned long long wd = wn; // (the next word one word ahead, as in pair_loop)
+                wn = nb64[((size_t)(min(k0 + 8, MAXNB / TPA - 8) >> 3) * C::NLIST + lrow(i)) * TPA + sub];
 #pragma unroll
                 for (int e0 = 0; e0 < 8; e0 += W) {
                     if (k0 + e0 == NM_PRIO_SW) prio_swap();
@@ -1903,8 +1905,10 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
             const double xi = __builtin_fma(px[i], invL, 0.5), yi = __builtin_fma(py[i], invL, 0.5), zi = __builtin_fma(pz[i], invL, 0.5), isi = rho[i];
             const int c = cnt[i];
             const int mine = (c - sub + TPA - 1) / TPA;
+            unsigned long long wn = nb64[(size_t)lrow(i) * TPA + sub];
             for (int k0 = 0; k0 < mine; k0 += 8) {
-                const unsigned long long wd = nb64[((size_t)(k0 >> 3) * C::NLIST + lrow(i)) * TPA + sub];
+                const unsigned long long wd = wn; // (the next word one word ahead, as in pair_loop)
+                wn = nb64[((size_t)(min(k0 + 8, MAXNB / TPA - 8) >> 3) * C::NLIST + lrow(i)) * TPA + sub];
 #pragma unroll
                 for (int e0 = 0; e0 < 8; e0 += W) {
                     if (k0 + e0 == NM_PRIO_SW) prio_swap();
