@@ -3,15 +3,17 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
 #include <random>
 #define NM_HD
 #include "nm_math.h"
 static double ulp_of(double x) { int e; frexp(x, &e); return ldexp(1.0, e - 53); }
-int main()
+int main(int argc, char **argv)
 {
+    const long N = argc > 1 ? atol(argv[1]) : 20000000;
     std::mt19937_64 g(1);
     double worst_log = 0, worst_s = 0, worst_c = 0; const double twopi = 6.283185307179586476925286766559;
-    for (long n = 0; n < 20000000; ++n) {
+    for (long n = 0; n < N; ++n) {
         const uint64_t r = g();
         const double u = (double)(r >> 11) * 0x1p-53;   // [0, 1)
         const double x = 1.0 - u;
@@ -27,5 +29,5 @@ int main()
     // the small end of log's argument
     for (int e = 1; e <= 53; ++e) { const double x = ldexp(1.0, -e); worst_log = std::fmax(worst_log, std::fabs(nm::log_pos(x) - std::log(x)) / ulp_of(std::log(x))); }
     printf("worst error in ulps of the libm result: log %.2f  sin %.2f  cos %.2f\n", worst_log, worst_s, worst_c);
-    return 0;
+    return (worst_log <= 1.0 && worst_s <= 1.0 && worst_c <= 1.0) ? 0 : 2;
 }
