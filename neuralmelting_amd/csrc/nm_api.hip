@@ -360,7 +360,7 @@ int pick_q(nm_ctx *c, int qmax, std::string &note)
     // end within a few ms of one another.  Measured on C5's per-GPU share (128 x 2048 atoms): equilibrated chains 221 k sweeps/s against
     // 211 k for the resident grid (+4.5 %: 74 ms per launch where perfect packing of the same blocks would give 67), but 276 k against
     // 324 k while all replicas are still alike (nothing to even out, and 4 workgroups per replica cost 1.27x the CU time of 2).  So it
-    // is opt-in: NM_OVERSUBSCRIBE=1.  (It also leans on workgroups being dispatched in index order within an XCD, which HIP does not
+    // is opt-in: NM_OVERSUBSCRIBE=1 (and a hundred cycles on, 203 k against 219 k: the gain belongs to the cycles in which the replicas differ most).  (It also leans on workgroups being dispatched in index order within an XCD, which HIP does not
     // promise; a cluster whose members do not gather fails its census and the block is re-issued on the resident grid, settle().)
     bool try_over = false;
     if (const char *e = std::getenv("NM_OVERSUBSCRIBE")) try_over = c->kind == 2 && qmax >= 4 && std::atoi(e) != 0;
