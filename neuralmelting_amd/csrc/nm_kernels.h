@@ -1314,7 +1314,12 @@ struct Replica {
     }
     __device__ __forceinline__ void check_atom(ListCheck &c, int i, double x, double y, double z) const
     {
-        double dx = x - c.sc * x0[i], dy = y - c.sc * y0[i], dz = z - c.sc * z0[i];
+        check_atom(c, x, y, z, x0[i], y0[i], z0[i]);
+    }
+    // (the reference position handed in: a caller that waits for something else first reads it before that wait)
+    __device__ __forceinline__ void check_atom(ListCheck &c, double x, double y, double z, double rx, double ry, double rz) const
+    {
+        double dx = x - c.sc * rx, dy = y - c.sc * ry, dz = z - c.sc * rz;
         dx -= L * rint(dx * c.invL); dy -= L * rint(dy * c.invL); dz -= L * rint(dz * c.invL);
         if (dx * dx + dy * dy + dz * dz > c.thr2) c.bad = 1;
     }
@@ -1357,9 +1362,11 @@ struct Replica {
                 const int i = o < a0 ? o : o + nown;
                 double *const g3[3] = { xg + 2 * (size_t)i, xg + 2 * (size_t)(NMAX + i), xg + 2 * (size_t)(2 * NMAX + i) };
                 double x3[3];
+                const double rx = x0[i], ry = y0[i], rz = z0[i]; // (read before the poll: at 8^3 they come from the global spill, a memory latency that
+                // now lies under the granules' round trip instead of behind it)
                 if (get_granules<3>(g3, mg, x3, timeout, poisoned)) {
                     px[i] = x3[0]; py[i] = x3[1]; pz[i] = x3[2];
-                    check_atom(c, i, x3[0], x3[1], x3[2]);
+                    check_atom(c, x3[0], x3[1], x3[2], rx, ry, rz);
                 }
             }
             ++gen;
