@@ -10,10 +10,13 @@ Workloads (--config; BASELINE.json `configs`):
   C4    Al (Sutton-Chen EAM, metal units) 4^3 cells, 8x8 grid
   C5    LJ 8^3 cells (2048 atoms), 32x32 grid over 8 GPUs: one GPU's share = 4 rows x 32 temperatures
   runsh LJ 5^3 cells (500 atoms), 32x32 grid: the reference's own production setting (run.sh:1,7,10), whole grid on one GPU
---scaling weak (default): every rank holds `rows` pressure rows of a (rows x N)-row grid, so per-GPU work is fixed; the exchange
-never leaves a pressure row, so there is no data-path collective.  --scaling strong: the config's own grid (C2: 8x8) is
-dealt out over the ranks — whole rows while they last, else even slot ranges with the split-row exchange over RCCL
-(neuralmelting_amd/exchange.py).
+One GPU: the preset as it stands.  --gpus N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): BOTH scaling legs
+run back to back — `value` is the STRONG-scaling rate of the preset's own grid (BASELINE.json's metric: "8x8 PxT grid, 1/2/4/8 GPUs";
+C2: whole pressure rows per rank while N <= 8, else even slot ranges with the split-row exchange over RCCL,
+neuralmelting_amd/exchange.py), and the WEAK-scaling rate of the grid with N times as many pressure rows (every rank holds `rows`
+rows, per-GPU work fixed; the exchange never leaves a pressure row, so there is no data-path collective) is reported under the key
+`weak`; each leg carries its own replicas_total and world_size_seen_by_backend.  --scaling weak|strong runs one leg only.
+--record adds a timed region with the reference's outputs on (thermo rows and trajectory frames written every cycle).
 """
 import argparse
 import json
@@ -41,13 +44,16 @@ CONFIGS = {
 }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--config', type=str, default='C2', choices=sorted(CONFIGS), help='workload preset (see the module docstring)')
-    ap.add_argument('--scaling', type=str, default='weak', choices=('weak', 'strong'))
+    ap.add_argument('--scaling', type=str, default=None, choices=('weak', 'strong'),
+                    help='default: one GPU runs the preset as it stands; at --gpus N > 1 BOTH legs run — `value` is the strong-scaling rate of the '
+                         "preset's own grid (the grid BASELINE's metric names), the weak-scaling rate of the N-times-larger grid is reported "
+                         'under the key `weak`.  Given explicitly, only that leg runs.')
     ap.add_argument('--sz', type=int, default=None, help='override: supercell size (-ss)')
     ap.add_argument('--rows', type=int, default=None, help='override: pressure rows per GPU')
     ap.add_argument('--tn', type=int, default=None, help='override: temperatures (-tn)')
@@ -60,7 +66,13 @@ def main():
                     'mean HMC acceptance is within 0.4-0.6, then times `steps` cycles again (the sustained rate = `value`); 0 = window only')
     ap.add_argument('--force-split', action='store_true', help='strong scaling: use the split-row (collective) exchange even where whole rows would do')
     ap.add_argument('--cpu-seconds', type=float, default=6.0, help='target wall time of each cpu_baseline leg')
-    args = ap.parse_args()
+    ap.add_argument('--record', action='store_true',
+                    help="one more timed region of `steps` cycles with the reference's outputs ON (-sc 0, remcmc:983-985): every cycle's thermo row "
+                         'and trajectory frame of every replica goes D2H and is appended to its .thrm / .traj file (nm_append_outputs), '
+                         'overlapped with the next block as the driver does; `value` is then the recorded rate, `record` holds both rates '
+                         'and the I/O share')
+    ap.add_argument('--record-dir', type=str, default=None, help='where --record writes (default: a temporary directory, removed afterwards)')
+    args = ap.parse_args(argv)
     if args.iterative:
         # The reference's iterative position move never undoes a rejected trial while its step size keeps growing (remcmc:522-545,
         # 733-737): from about cycle 10 on atoms overlap, energies reach 1e12-1e18 per atom and sooner or later leave the floating-point
@@ -68,13 +80,13 @@ def main():
         args.equil = 0
         if (args.warmup, args.steps) == (ap.get_default('warmup'), ap.get_default('steps')):
             args.warmup, args.steps = 3, 5   # cycles 3-7: before the chains leave the floating-point range
+    return args
 
-    el, sz, rows, np_cfg, tn, mod, desc = CONFIGS[args.config]
-    custom = any(v is not None for v in (args.sz, args.rows, args.tn, args.mod, args.el))
-    el, sz, rows, tn, mod = args.el or el, args.sz or sz, args.rows or rows, args.tn or tn, args.mod or mod
-    if custom:
-        np_cfg, desc = rows, 'custom workload'
 
+def main(argv=None, make_engine=None):
+    """make_engine: tests only (tests/_mp_bench.py hands in a stand-in with the Engine interface so that the N > 1 logic runs on CPUs
+    over gloo); the product path builds neuralmelting_amd.Engine and fails loudly without libnm_hip.so / a HIP device."""
+    args = parse_args(argv)
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -83,6 +95,7 @@ def main():
             raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...'
                              % (args.gpus, args.gpus))
     import torch
+    have_gpu = torch.cuda.is_available()
     dist = None
     backend = None
     if world > 1 or 'RANK' in os.environ:  # under torch.distributed.run: one rank per GPU over RCCL (also at N=1)
@@ -95,16 +108,52 @@ def main():
             torch.cuda.set_device(local)
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
         else:
-            local = local % max(torch.cuda.device_count(), 1)
-            torch.cuda.set_device(local)
+            if have_gpu:
+                local = local % max(torch.cuda.device_count(), 1)
+                torch.cuda.set_device(local)
             dist.init_process_group(backend)
+    env = dict(rank=rank, world=world, local=local, dist=dist, backend=backend, have_gpu=have_gpu, make_engine=make_engine)
+
+    # Which legs.  One GPU: the preset as it stands (`scaling` "weak" by the contract's definition: per-GPU work fixed).  N > 1 without
+    # --scaling: the metric's own grid dealt out over the ranks (strong scaling: BASELINE.json's "8x8 PxT grid, 1/2/4/8 GPUs") is
+    # `value`; the grid of N times as many pressure rows (weak scaling) rides along under `weak`.
+    if args.scaling is not None:
+        out = run_leg(args, env, args.scaling, with_cpu=not args.no_cpu)
+    elif world == 1:
+        out = run_leg(args, env, 'weak', with_cpu=not args.no_cpu)
+    else:
+        out = run_leg(args, env, 'strong', with_cpu=not args.no_cpu)
+        weak = run_leg(args, env, 'weak', with_cpu=False)
+        if rank == 0:
+            out['weak'] = {k: weak[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'scaling', 'window', 'sustained')}
+            out['weak'].update({k: weak['config'][k] for k in ('workload', 'replicas_per_gpu', 'replicas_total', 'sweeps_per_step',
+                                                               'parallelism', 'world_size_seen_by_backend', 'backend')})
+            out['weak']['roofline_frac'] = weak['roofline']['frac']
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+    return out
+
+
+def run_leg(args, env, scaling, with_cpu):
+    """one workload (grid) on all ranks: warm-up, the timed window, equilibration, the timed sustained region; rank 0 returns the line"""
+    import torch
+    rank, world, local, dist, backend = env['rank'], env['world'], env['local'], env['dist'], env['backend']
+    el, sz, rows, np_cfg, tn, mod, desc = CONFIGS[args.config]
+    custom = any(v is not None for v in (args.sz, args.rows, args.tn, args.mod, args.el))
+    el, sz, rows, tn, mod = args.el or el, args.sz or sz, args.rows or rows, args.tn or tn, args.mod or mod
+    if custom:
+        np_cfg, desc = rows, 'custom workload'
 
     import neuralmelting_amd as nm
     from neuralmelting_amd import lattice, exchange as X
+    make_engine = env['make_engine'] or nm.Engine
 
     # ---- which replicas this rank holds
     split = False
-    if args.scaling == 'weak':
+    if scaling == 'weak':
         npn = rows * world
         row0, nrows = rank * rows, rows
     else:
@@ -127,10 +176,10 @@ def main():
         x, v, box, d = lattice.init_states(sz, P, T, 0.03125, 0.03125, el=el, row0=r0, nrows=r1 - r0 + 1)
         a = k0 - r0 * tn
         x, v, box, d = x[a:a + nloc], v[a:a + nloc], box[a:a + nloc], d[a:a + nloc]
-        eng = nm.Engine(natoms, P, T, slot0=k0, nslots=nloc, **kw)
+        eng = make_engine(natoms, P, T, slot0=k0, nslots=nloc, **kw)
     else:
         x, v, box, d = lattice.init_states(sz, P, T, 0.03125, 0.03125, el=el, row0=row0, nrows=nrows)
-        eng = nm.Engine(natoms, P, T, row0=row0, nrows=nrows, **kw)
+        eng = make_engine(natoms, P, T, row0=row0, nrows=nrows, **kw)
         k0 = row0 * tn
     eng.set_state(x, v, box, d)
     ns = eng.nslots
@@ -144,9 +193,13 @@ def main():
         """a pressure row spans ranks: all-gather (E_tot, V), identical sweep everywhere, the swapped replicas move (exchange.py)"""
         X.exchange_split(eng, step, npn, tn, 256, k0, natoms, et_all, pf_all, info, rank=rank)
 
+    recorder = None
+
     def cycle(step):
         eng.set_step(step)
         eng.run_block(mod)
+        if recorder is not None:
+            recorder.cycle(eng)          # the previous cycle's files are written while this block runs; this cycle's rows and frames go D2H
         eng.adapt()
         if split:
             exchange_split(step)
@@ -155,30 +208,38 @@ def main():
 
     def fence():
         eng.synchronize()
-        torch.cuda.synchronize()
+        if env['have_gpu']:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            if env['have_gpu']:
+                torch.cuda.synchronize()
+
+    def reduce_(vals, op):
+        tt = torch.tensor(vals, dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(tt, op=op)
+        return [float(q) for q in tt.tolist()]
 
     def timed(nsteps, step):
         """exactly nsteps cycles between two fences; (seconds = max over ranks, replicas of all ranks, kernel launches, kernel ms, stats)"""
         fence()
         eng.timing_reset()
         eng.stats(reset=True)
+        heals0 = getattr(eng, 'heals', 0)
         t0 = time.perf_counter()
         for _ in range(nsteps):
             cycle(step)
             step += 1
+        if recorder is not None:
+            recorder.flush()
         fence()
         dt = time.perf_counter() - t0
         ns_total = ns
         if dist is not None:
-            tt = torch.tensor([dt, float(ns)], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
-            dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
-            dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)
-            dt, ns_total = float(tt[0].item()), int(round(float(tt[1].item())))
+            dt = reduce_([dt], dist.ReduceOp.MAX)[0]
+            ns_total = int(round(reduce_([float(ns)], dist.ReduceOp.SUM)[0]))
         launches, kms = eng.timing()
-        return step, dt, ns_total, launches, kms, eng.stats()
+        return step, dt, ns_total, launches, kms, eng.stats(), getattr(eng, 'heals', 0) - heals0
 
     def hmc_acceptance(step):
         """mean HMC acceptance over this rank's replicas of one more (untimed) cycle; agreed over the ranks"""
@@ -191,9 +252,7 @@ def main():
         else:
             eng.exchange(count=False)
         if dist is not None:
-            tt = torch.tensor([a], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
-            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-            a = float(tt.item()) / dist.get_world_size()
+            a = reduce_([a], dist.ReduceOp.SUM)[0] / dist.get_world_size()
         return a
 
     step = 0
@@ -201,7 +260,7 @@ def main():
         cycle(step)
         step += 1
     # ---- the window right after the warm-up the caller asked for (what rounds 1 and 2 reported)
-    step, dt_w, ns_total, launches_w, kms_w, st_w = timed(args.steps, step)
+    step, dt_w, ns_total, launches_w, kms_w, st_w, heals_w = timed(args.steps, step)
     # ---- untimed equilibration, then the same number of timed cycles: the sustained rate
     equil = 0
     if args.equil > 0:
@@ -212,9 +271,22 @@ def main():
             acc = hmc_acceptance(step)
             step += 1
             equil += 1
-        step, dt, ns_total, launches, kms, st = timed(args.steps, step)
+        step, dt, ns_total, launches, kms, st, heals_s = timed(args.steps, step)
     else:
-        dt, launches, kms, st = dt_w, launches_w, kms_w, st_w
+        dt, launches, kms, st, heals_s = dt_w, launches_w, kms_w, st_w, heals_w
+    # ---- the same number of cycles once more with the reference's outputs ON (--record)
+    rec = None
+    if args.record:
+        import shutil
+        import tempfile
+        rdir = args.record_dir or tempfile.mkdtemp(prefix='nm_record_')
+        os.makedirs(rdir, exist_ok=True)
+        recorder = Recorder(rdir, k0, ns, natoms)
+        step, dt_r, _, launches_r, kms_r, st_r, _ = timed(args.steps, step)
+        rec = recorder.summary(args.steps)
+        recorder = None
+        if args.record_dir is None:
+            shutil.rmtree(rdir, ignore_errors=True)
     world_seen = dist.get_world_size() if dist is not None else 1
 
     # one more block outside the timed region, read before gen_mc_params zeroes the counters: the per-replica acceptance
@@ -222,8 +294,6 @@ def main():
     eng.set_step(step)
     eng.run_block(mod)
     last = eng.thermo()
-    sweeps_total = ns_total * mod * args.steps
-    value = sweeps_total / dt
 
     out = None
     if rank == 0:
@@ -235,7 +305,7 @@ def main():
 
         def numbers(dt_, launches_, kms_, st_):
             """rate, kernel time and roofline figures of one timed region of args.steps cycles"""
-            k_avg_s = (kms_ / max(launches_, 1)) * 1e-3
+            k_avg_s = max((kms_ / max(launches_, 1)) * 1e-3, 1e-12)
             evals = st_[:, 0].sum()
             mean_pairs = st_[:, 3].sum() / max(st_[:, 2].sum(), 1.0)
             flop_alg_launch = evals_alg * sweeps_per_launch * mean_pairs * FLOP_PER_PAIR
@@ -244,8 +314,8 @@ def main():
                     'kernel_avg_ms': k_avg_s * 1e3, 'launches': launches_,
                     'achieved': flop_alg_launch / k_avg_s / 1e12, 'frac': flop_alg_launch / k_avg_s / 1e12 / FP64_VEC_PEAK_TF,
                     'algorithmic_flop_per_launch': flop_alg_launch,
-                    'executed': evals * mean_pairs * FLOP_PER_PAIR / (kms_ * 1e-3) / 1e12,
-                    'frac_executed': evals * mean_pairs * FLOP_PER_PAIR / (kms_ * 1e-3) / 1e12 / FP64_VEC_PEAK_TF,
+                    'executed': evals * mean_pairs * FLOP_PER_PAIR / max(kms_ * 1e-3, 1e-12) / 1e12,
+                    'frac_executed': evals * mean_pairs * FLOP_PER_PAIR / max(kms_ * 1e-3, 1e-12) / 1e12 / FP64_VEC_PEAK_TF,
                     'evals_per_sweep': evals / (ns * mod * args.steps), 'mean_pairs_per_eval': mean_pairs,
                     'list_rebuilds_per_sweep': st_[:, 1].sum() / (ns * mod * args.steps),
                     'hbm_gbs_algorithmic': bytes_per_sweep * sweeps_per_launch / k_avg_s / 1e9,
@@ -258,18 +328,18 @@ def main():
         prof = measured_profile((args.config + ('_iter' if args.iterative else '')) if not custom else None, ns, mod)
         grid = '%dx%d PxT grid%s' % (npn, tn, '' if world == 1 else ' over %d GPUs' % world)
         metric = 'MC sweeps/sec (whole node), %s %d^3 cells, %s' % (el, sz, grid)
+        keys = ('value', 'ms_per_step', 'kernel_avg_ms', 'frac', 'frac_executed', 'evals_per_sweep', 'list_rebuilds_per_sweep',
+                'slot_block_ms_mean', 'slot_block_ms_max')
         out = {
             # value = the SUSTAINED rate: `steps` timed cycles of equilibrated chains (HMC accepting about half its trajectories, step
             # sizes adapted).  `window` = the same number of cycles timed right after `warmup` cycles from the lattice start, where
             # trajectories are still short and lists are rebuilt less often: what rounds 1 and 2 reported as value.
             'metric': metric, 'value': sus['value'], 'unit': 'sweeps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': sus['ms_per_step'], 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
+            'ms_per_step': sus['ms_per_step'], 'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'equilibration_cycles': equil, 'timed_from_cycle': step - args.steps if args.equil > 0 else args.warmup,
-            'window': {k: win[k] for k in ('value', 'ms_per_step', 'kernel_avg_ms', 'frac', 'frac_executed', 'evals_per_sweep',
-                                           'list_rebuilds_per_sweep', 'slot_block_ms_mean', 'slot_block_ms_max')},
-            'sustained': {k: sus[k] for k in ('value', 'ms_per_step', 'kernel_avg_ms', 'frac', 'frac_executed', 'evals_per_sweep',
-                                              'list_rebuilds_per_sweep', 'slot_block_ms_mean', 'slot_block_ms_max')},
+            'equilibration_cycles': equil, 'timed_from_cycle': step - args.steps * (2 if args.record else 1) if args.equil > 0 else args.warmup,
+            'window': {k: win[k] for k in keys},
+            'sustained': {k: sus[k] for k in keys},
             'config': {'workload': '%s; %s %d^3 cells (%d atoms), %d replicas on rank 0 (%d in all), MOD=%d, %s PMC 0.125 / VMC '
                                    '0.125 / HMC 0.75 x 8 steps, outputs off' % (desc, el, sz, natoms, ns, ns_total, mod,
                                                                                'iterative' if args.iterative else 'bulk'),
@@ -282,8 +352,9 @@ def main():
             # kernel's HIP-event time over the timed (sustained) region; executed = what the kernel actually evaluated (it keeps forces
             # across moves: ~6.26 evaluations per sweep); traffic = HBM bytes per launch from the committed rocprofv3 PMC passes.
             'roofline': {'bound': 'fp64-valu', 'achieved': sus['achieved'], 'peak': FP64_VEC_PEAK_TF, 'unit': 'TFLOP/s',
-                         'frac': sus['frac'], 'traffic': prof.get('traffic'),
+                         'frac': sus['frac'], 'traffic': prof.get('traffic'), 'traffic_range': prof.get('traffic_range'),
                          'kernel': 'nm_block_kernel', 'kernel_avg_ms': sus['kernel_avg_ms'], 'launches': sus['launches'],
+                         'launches_that_did_no_work': heals_s,   # blocks re-issued at fewer workgroups per replica inside the region (not in kernel_avg_ms)
                          'algorithmic_flop_per_launch': sus['algorithmic_flop_per_launch'], 'algorithmic_evals_per_sweep': evals_alg,
                          'executed': sus['executed'], 'frac_executed': sus['frac_executed'], 'evals_per_sweep': sus['evals_per_sweep'],
                          'mean_pairs_per_eval': sus['mean_pairs_per_eval'], 'flop_per_pair': FLOP_PER_PAIR,
@@ -296,20 +367,84 @@ def main():
                              'frac': sus['hbm_gbs_algorithmic'] / HBM_PEAK_GBS, 'traffic': prof.get('traffic'),
                              'algorithmic_bytes_per_launch': bytes_per_sweep * sweeps_per_launch},
         }
+        if rec is not None:
+            on = ns_total * mod * args.steps / dt_r
+            out['record'] = dict(rec, outputs_off=sus['value'], outputs_on=on, io_share=1.0 - on / sus['value'],
+                                 ms_per_step_on=dt_r / args.steps * 1e3, kernel_avg_ms_on=kms_r / max(launches_r, 1),
+                                 note='rank 0; every cycle: thermo rows + positions D2H, 17-column .thrm row and N+1-line .traj frame per replica '
+                                      'appended by nm_append_outputs (remcmc:235-256) on a helper thread while the next block runs')
+            out['value'], out['ms_per_step'] = on, dt_r / args.steps * 1e3
+            out['metric'] = metric + ' (outputs on)'
+            out['config']['workload'] = out['config']['workload'].replace('outputs off', 'outputs ON every cycle (-sc 0)')
         out['replicas'] = {'note': 'rank 0, block after the timed region, slot k = i*NT + j (pressure i, temperature j)',
                            'accept_pmc': [round(float(a), 3) for a in last[:, 14]],
                            'accept_vmc': [round(float(a), 3) for a in last[:, 15]],
                            'accept_hmc': [round(float(a), 3) for a in last[:, 16]],
                            'pe_per_atom': [round(float(a) / natoms, 4) for a in last[:, 1]],
                            'vol_per_atom': [round(float(a) / natoms, 4) for a in last[:, 4]]}
-        if not args.no_cpu:
+        if with_cpu:
             out['cpu_baseline'] = cpu_baseline(eng, natoms, el, mod, T, tn, k0, args.cpu_seconds, bulk=not args.iterative)
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
     eng.close()
-    if rank == 0:
-        print(json.dumps(out))
+    return out
+
+
+class Recorder:
+    """write_outputs (remcmc:259-286) for the bench's --record leg: per cycle the thermo rows and the positions of this rank's replicas go
+    D2H and one .thrm row + one .traj frame per replica are appended (nm_append_outputs, threaded C formatter) on a helper thread while
+    the GPU runs the next block — what neuralmelting_amd/remcmc.py's main loop does with -sc 0"""
+
+    def __init__(self, rdir, k0, ns, natoms):
+        import ctypes as C
+        from neuralmelting_amd import _lib as B
+        self.B, self.C, self.ns, self.natoms = B, C, ns, natoms
+        self.thrm = (C.c_char_p * ns)(*[os.path.join(rdir, 'bench.%04d.thrm' % (k0 + k)).encode() for k in range(ns)])
+        self.traj = (C.c_char_p * ns)(*[os.path.join(rdir, 'bench.%04d.traj' % (k0 + k)).encode() for k in range(ns)])
+        self.pending, self.thread, self.err = None, None, None
+        self.d2h_s = self.write_s = 0.0
+        self.bytes = 0
+
+    def _write(self, rows, x, box):
+        t0 = time.perf_counter()
+        B = self.B
+        rc = B.load().nm_append_outputs(self.ns, self.natoms, self.thrm, self.traj, rows.ctypes.data_as(B.c_double_p),
+                                        x.ctypes.data_as(B.c_double_p), box.ctypes.data_as(B.c_double_p), 0)
+        if rc != 0:
+            self.err = IOError('nm_append_outputs failed (%d)' % rc)
+        self.write_s += time.perf_counter() - t0
+
+    def _join(self):
+        if self.thread is not None:
+            self.thread.join()
+            self.thread = None
+            if self.err is not None:
+                raise self.err
+
+    def cycle(self, eng):
+        """called right after run_block was enqueued: start writing the PREVIOUS cycle, then fetch this one (waits for the block)"""
+        import threading
+        if self.pending is not None:
+            self._join()
+            self.thread = threading.Thread(target=self._write, args=self.pending)
+            self.thread.start()
+            self.pending = None
+        t0 = time.perf_counter()
+        xs, _, boxs, _ = eng.get_state(velocities=False)
+        rows = eng.thermo()
+        self.d2h_s += time.perf_counter() - t0     # (includes waiting for the block itself)
+        self.pending = (np.ascontiguousarray(rows), np.ascontiguousarray(xs), np.ascontiguousarray(boxs))
+        self.bytes += self.ns * (17 * 11 + 1 + (self.natoms + 1) * 34)   # ' %.4E' = 11 bytes per number
+
+    def flush(self):
+        self._join()
+        if self.pending is not None:
+            self._write(*self.pending)
+            self.pending = None
+
+    def summary(self, steps):
+        return {'write_ms_per_step': self.write_s / steps * 1e3, 'fetch_ms_per_step_incl_block_wait': self.d2h_s / steps * 1e3,
+                'text_bytes_per_step': self.bytes // max(steps, 1)}
 
 
 def measured_profile(config, ns, mod):
@@ -320,7 +455,7 @@ def measured_profile(config, ns, mod):
     if config is None:
         return {}
     f = None
-    for rnd in ('r03', 'r02'):   # this round's passes; an older round's file is still labelled with the commit it belongs to
+    for rnd in ('r04', 'r03', 'r02'):   # this round's passes; an older round's file is still labelled with the commit it belongs to
         g = os.path.join(ROOT, 'profiles', '%s_pmc_block_kernel_%s.json' % (rnd, config))
         if os.path.isfile(g):
             f = g
@@ -334,6 +469,13 @@ def measured_profile(config, ns, mod):
     out = {'source': 'profiles/' + os.path.basename(f), 'commit': meta.get('commit')}
     if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
         out['traffic'] = (2.0 * d['FETCH_SIZE']['mean'] + d['WRITE_SIZE']['mean']) * 1024.0
+        # min - max over the profiled launches and over the round's other profile runs of this preset (the cluster kernels' write-back of
+        # hand-over lines moves the figure by up to 2x from run to run with unchanged kernels: quote a range, not a point)
+        lo = (2.0 * d['FETCH_SIZE']['min'] + d['WRITE_SIZE']['min']) * 1024.0
+        hi = (2.0 * d['FETCH_SIZE']['max'] + d['WRITE_SIZE']['max']) * 1024.0
+        for extra in meta.get('traffic_other_runs', []):
+            lo, hi = min(lo, extra), max(hi, extra)
+        out['traffic_range'] = [lo, hi]
     if 'SQ_ACTIVE_INST_VALU' in d and 'GRBM_GUI_ACTIVE' in d:
         # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
         cyc = d['GRBM_GUI_ACTIVE']['mean'] / 8.0

@@ -76,6 +76,8 @@ const char *nm_create_note(const nm_ctx *ctx); /* not an error: what the residen
 int nm_nslots(const nm_ctx *ctx);              /* nrows*nt replicas held by this context               */
 int nm_natoms(const nm_ctx *ctx);
 int nm_cus_per_replica(const nm_ctx *ctx);     /* workgroups (CUs) cooperating on one replica: 1, 2, 4 ...  */
+int nm_heal_count(const nm_ctx *ctx);          /* blocks re-issued at fewer workgroups per replica so far (see nm_get_status): a timed region
+                                                  during which this grew contained launches that did no work (they are not in nm_timing_get)  */
 
 /* thermodynamic constants per local slot: et = k_B T, pf = P/(k_B T) (init_constant, remcmc:114-132) */
 int nm_get_const(const nm_ctx *ctx, double *et, double *pf);
@@ -84,6 +86,13 @@ int nm_get_const(const nm_ctx *ctx, double *et, double *pf);
 int nm_set_state(nm_ctx *ctx, int k0, int nk, const double *x, const double *v, const double *box,
                  const double *dxdvdt);
 int nm_get_state(nm_ctx *ctx, int k0, int nk, double *x, double *v, double *box, double *dxdvdt);
+/* the same for the nk local slots listed in slots[] (any order), together with their thermo scalars th[nk][5] (nm_set_thermo's columns):
+   one settle, one wait for the whole batch.  Used by the split-row exchange, which re-seats only the replicas that swapped
+   (replica_exchange moves entries [0..11] of two state lists, remcmc:798).  Any data pointer may be NULL.  In nm_set_slots a box sets
+   the volume column, a th row given as well overrides it. */
+int nm_get_slots(nm_ctx *ctx, int nk, const int *slots, double *x, double *v, double *box, double *dxdvdt, double *th);
+int nm_set_slots(nm_ctx *ctx, int nk, const int *slots, const double *x, const double *v, const double *box, const double *dxdvdt,
+                 const double *th);
 
 /* init_samples (remcmc:394-456) for every local replica, for callers without the Python front end: fcc lattice in create_atoms
    order, box edge statically relaxed to the row's pressure (what fix box/relax + minimize converge to for the perfect crystal),
@@ -122,7 +131,10 @@ int nm_synchronize(nm_ctx *ctx);
      itself (NM_ST_NOT_RESIDENT, NM_ST_SYNC_TIMEOUT: the analogue of Dask retrying a failed task, remcmc:921-922), notes that in
      nm_create_note and returns NM_OK;
    - otherwise returns NM_ERR_STATE once, with the reason in nm_last_error; the bits stay readable here until the next block and the
-     context remains usable (e.g. after nm_set_state of a configuration that fits). */
+     context remains usable (e.g. after nm_set_state of a configuration that fits).
+   "nm_get_* / nm_set_*" means every entry point that reads or replaces what the queue works on: state, thermo, slots, stats, trace,
+   perm, exchange criteria, counters and both tapes.  nm_get_status itself looks too (a halted queue is re-issued) but always hands
+   out the bits and returns NM_OK: it is the call that reports them. */
 #define NM_ST_LIST_OVERFLOW 1   /* more neighbours within rc + skin than list slots                           */
 #define NM_ST_BOX_TOO_SMALL 2   /* box edge < 2 rc: outside the minimum-image regime                          */
 #define NM_ST_TAPE_EXHAUSTED 4  /* test-only rng tape too short                                               */

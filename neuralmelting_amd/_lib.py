@@ -15,7 +15,8 @@ NM_EL_LJ, NM_EL_AL = 0, 1
 NM_THERMO_COLS, NM_TRACE_COLS, NM_STATS_COLS = 17, 4, 10
 
 # every symbol include/nm.h declares (tests check that the library exports all of them)
-SYMBOLS = ('nm_create', 'nm_destroy', 'nm_last_error', 'nm_create_note', 'nm_nslots', 'nm_natoms', 'nm_cus_per_replica', 'nm_get_const',
+SYMBOLS = ('nm_create', 'nm_destroy', 'nm_last_error', 'nm_create_note', 'nm_nslots', 'nm_natoms', 'nm_cus_per_replica', 'nm_heal_count', 'nm_get_const',
+           'nm_get_slots', 'nm_set_slots',
            'nm_set_state', 'nm_get_state', 'nm_init_lattice', 'nm_lattice_state', 'nm_set_thermo', 'nm_set_step', 'nm_run_md', 'nm_run_block', 'nm_get_thermo', 'nm_adapt',
            'nm_exchange', 'nm_synchronize', 'nm_get_status', 'nm_format_thrm', 'nm_format_traj', 'nm_append_outputs', 'nm_timing_reset', 'nm_timing_get', 'nm_stats_get', 'nm_eval',
            'nm_set_rng_tape', 'nm_set_exchange_tape', 'nm_set_trace', 'nm_get_trace', 'nm_get_perm', 'nm_set_counters',
@@ -58,10 +59,13 @@ def load():
     L.nm_nslots.argtypes = [vp]
     L.nm_natoms.argtypes = [vp]
     L.nm_cus_per_replica.argtypes = [vp]
+    L.nm_heal_count.argtypes = [vp]
     L.nm_get_const.argtypes = [vp, c_double_p, c_double_p]
     L.nm_set_state.argtypes = [vp, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
     L.nm_get_state.argtypes = [vp, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
     L.nm_set_thermo.argtypes = [vp, C.c_int, C.c_int, c_double_p]
+    L.nm_get_slots.argtypes = [vp, C.c_int, c_int_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
+    L.nm_set_slots.argtypes = [vp, C.c_int, c_int_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     L.nm_init_lattice.argtypes = [vp, C.c_double, C.c_double, C.c_int]
     L.nm_lattice_state.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, C.c_uint32, C.c_int, C.c_double, C.c_int, c_double_p, c_double_p]
     L.nm_set_step.argtypes = [vp, C.c_uint32]

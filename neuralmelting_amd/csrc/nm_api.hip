@@ -55,7 +55,7 @@ typedef Cfg<512, 1, 2048, 224, unsigned short, false, false> CfgLarge;
 
 thread_local std::string g_create_error;
 
-struct EvPair { hipEvent_t a, b; bool used; };
+struct EvPair { hipEvent_t a, b; bool used; uint32_t launch_id; };
 
 } // namespace
 
@@ -313,7 +313,7 @@ int issue_block(nm_ctx *c, int kind, int arg, uint32_t step, int trace, const in
         HIPCHK(c, hipEventRecord(e.a, c->stream));
         HIPCHK(c, launch_kind(c, p));
         HIPCHK(c, hipEventRecord(e.b, c->stream));
-        e.used = true;
+        e.used = true; e.launch_id = c->launch_id;
         c->ev_next = (c->ev_next + 1) % (int)c->ev.size();
     } else HIPCHK(c, launch_kind(c, p));
     c->journal.push_back({ kind, arg, trace, step, c->launch_id });
@@ -396,15 +396,30 @@ int pick_q(nm_ctx *c, int qmax, std::string &note)
 // the buffers whose size depends on the workgroups per replica: the per-workgroup spill and the hand-over granules
 int alloc_cluster_buffers(nm_ctx *c)
 {
-    if (c->d_aux) { HIPCHK(c, hipFree(c->d_aux)); c->d_aux = nullptr; }
-    if (c->d_xbuf) { HIPCHK(c, hipFree(c->d_xbuf)); c->d_xbuf = nullptr; }
     const size_t ns = c->nslots;
-    if (c->kind == 0) c->aux_doubles = CfgSmall::AUX_DOUBLES;
-    else if (c->kind == 1) { c->aux_doubles = c->cus == 8 ? CfgMidQ8::AUX_DOUBLES : CfgMid::AUX_DOUBLES; c->lds_bytes = c->cus == 8 ? CfgMidQ8::LDS_BYTES : CfgMid::LDS_BYTES; }
-    else c->aux_doubles = CfgLarge::AUX_DOUBLES;
-    if (c->aux_doubles) HIPCHK(c, dalloc(&c->d_aux, ns * c->cus * c->aux_doubles));
+    size_t aux_doubles, lds_bytes = c->lds_bytes;
+    if (c->kind == 0) aux_doubles = CfgSmall::AUX_DOUBLES;
+    else if (c->kind == 1) { aux_doubles = c->cus == 8 ? CfgMidQ8::AUX_DOUBLES : CfgMid::AUX_DOUBLES; lds_bytes = c->cus == 8 ? CfgMidQ8::LDS_BYTES : CfgMid::LDS_BYTES; }
+    else aux_doubles = CfgLarge::AUX_DOUBLES;
+    // the new buffers first, swapped in only when both exist: a failure leaves the context with the buffers (and the workgroups per
+    // replica) it can still run with
+    double *aux = nullptr, *xbuf = nullptr;
     const size_t xbd = c->kind == 0 ? CfgSmall::XBUF_DOUBLES : c->kind == 1 ? CfgMid::XBUF_DOUBLES : CfgLarge::XBUF_DOUBLES;
-    if (c->cus > 1) { HIPCHK(c, dalloc(&c->d_xbuf, ns * 2 * xbd)); HIPCHK(c, hipMemset(c->d_xbuf, 0, ns * 2 * xbd * sizeof(double))); }
+    hipError_t e = hipSuccess;
+    if (aux_doubles) e = dalloc(&aux, ns * c->cus * aux_doubles);
+    if (e == hipSuccess && c->cus > 1) {
+        e = dalloc(&xbuf, ns * 2 * xbd);
+        if (e == hipSuccess) e = hipMemset(xbuf, 0, ns * 2 * xbd * sizeof(double));
+    }
+    if (e != hipSuccess) {
+        if (aux) hipFree(aux);
+        if (xbuf) hipFree(xbuf);
+        if (!c->d_xbuf) { c->cus = 1; c->over = false; } // nothing to hand over with: one workgroup per replica (its spill area, if any, is a subset of what is there)
+        return fail(c, NM_ERR_HIP, std::string("alloc_cluster_buffers: ") + hipGetErrorString(e));
+    }
+    if (c->d_aux) hipFree(c->d_aux);
+    if (c->d_xbuf) hipFree(c->d_xbuf);
+    c->d_aux = aux; c->d_xbuf = xbuf; c->aux_doubles = aux_doubles; c->lds_bytes = lds_bytes;
     return NM_OK;
 }
 
@@ -446,11 +461,17 @@ int settle(nm_ctx *c)
                           c->journal[at].step, q_old, (any & ST_NOT_RESIDENT) ? "grid not resident" : "hand-over timed out", c->cus, why.c_str());
             c->note += buf;
             ++c->heals;
+            // timing: the launch that halted did nothing for the replicas that are re-issued, and the blocks queued behind it found the
+            // halt word armed and left at once — their event pairs would count launches that did no work.  Drop them (first wait for them:
+            // an event pair is recycled) and time the re-issued blocks instead, so that nm_timing_get keeps meaning "the launches that did
+            // the work".  nm_heal_count tells a caller that a region contained a re-issue.
+            for (auto &e : c->ev)
+                if (e.used && e.launch_id >= c->journal[at].launch_id) { hipEventSynchronize(e.b); e.used = false; }
             std::vector<nm_ctx::Op> todo(c->journal.begin() + at, c->journal.end());
             c->journal.clear();
             for (size_t k = 0; k < todo.size(); ++k) {
                 const nm_ctx::Op &o = todo[k];
-                if (o.kind == OP_BLOCK || o.kind == OP_MD) rc = issue_block(c, o.kind, o.arg, o.step, o.trace, k == 0 ? c->d_rerun : nullptr, false);
+                if (o.kind == OP_BLOCK || o.kind == OP_MD) rc = issue_block(c, o.kind, o.arg, o.step, o.trace, k == 0 ? c->d_rerun : nullptr, o.kind == OP_BLOCK);
                 else if (o.kind == OP_ADAPT) rc = issue_adapt(c);
                 else rc = issue_exchange(c, o.step);
                 if (rc) return rc;
@@ -476,6 +497,21 @@ int check_status(nm_ctx *c)
     return settle(c);
 }
 
+// everything a context owns; safe on a half-built one (nm_create's failure paths: `new nm_ctx()` zero-initialises the pointers)
+void free_ctx(nm_ctx *c)
+{
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto &e : c->ev) { if (e.a) hipEventDestroy(e.a); if (e.b) hipEventDestroy(e.b); }
+    void *ptrs[] = { c->d_x, c->d_v, c->d_box, c->d_steps, c->d_therm, c->d_count, c->d_ratio, c->d_et, c->d_pf, c->d_tq,
+                     c->d_stats, c->d_slot2buf, c->d_status, c->d_nswaps, c->d_evalU, c->d_evalW, c->d_evalF, c->d_xcrit,
+                     c->d_xtape, c->d_tape, c->d_tape_off, c->d_trace, c->d_nbr, c->d_aux, c->d_prof, c->d_tline, c->d_xbuf, c->d_census,
+                     c->d_status_acc, c->d_halt, c->d_rerun, c->d_order, c->d_last_ticks };
+    for (void *q : ptrs) if (q) hipFree(q);
+    if (c->h_stage) hipHostFree(c->h_stage);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
 } // namespace
 
 extern "C" {
@@ -485,6 +521,7 @@ const char *nm_create_note(const nm_ctx *ctx) { return ctx ? ctx->note.c_str() :
 int nm_nslots(const nm_ctx *ctx) { return ctx ? ctx->nslots : NM_ERR_ARG; }
 int nm_natoms(const nm_ctx *ctx) { return ctx ? ctx->N : NM_ERR_ARG; }
 int nm_cus_per_replica(const nm_ctx *ctx) { return ctx ? ctx->cus : NM_ERR_ARG; }
+int nm_heal_count(const nm_ctx *ctx) { return ctx ? ctx->heals : NM_ERR_ARG; }
 
 int nm_create(const nm_config *cfg, nm_ctx **out)
 {
@@ -566,7 +603,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
         hipError_t e_ = (call);                                                                       \
         if (e_ != hipSuccess) {                                                                       \
             fail(nullptr, NM_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));             \
-            delete c;                                                                                 \
+            free_ctx(c);                                                                              \
             return NM_ERR_HIP;                                                                        \
         }                                                                                             \
     } while (0)
@@ -595,7 +632,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
             for (int k = 0; k < c->nslots; ++k) ident[k] = k;
             CHK(hipMemcpy(c->d_slot2buf, ident.data(), sizeof(int) * c->nslots, hipMemcpyHostToDevice));
         }
-        if (pick_q(c, want, note) != NM_OK) { g_create_error = c->err; delete c; return NM_ERR_HIP; } // (workgroups per replica: see pick_q)
+        if (pick_q(c, want, note) != NM_OK) { g_create_error = c->err; free_ctx(c); return NM_ERR_HIP; } // (workgroups per replica: see pick_q)
         if (!note.empty()) note = "nm_create: " + note;
         {
             hipDeviceProp_t prop;
@@ -624,7 +661,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
 #endif
     c->d_tape = nullptr; c->d_tape_off = nullptr; c->d_trace = nullptr; c->d_nbr = nullptr;
     if (nbr_elems) CHK(hipMalloc(&c->d_nbr, ns * 2 * nbr_elems * sizeof(unsigned short))); // two lists per slot (Cfg::LIST2)
-    if (alloc_cluster_buffers(c) != NM_OK) { g_create_error = c->err; delete c; return NM_ERR_HIP; }
+    if (alloc_cluster_buffers(c) != NM_OK) { g_create_error = c->err; free_ctx(c); return NM_ERR_HIP; }
     CHK(hipMemset(c->d_x, 0, ns * n3 * sizeof(double))); CHK(hipMemset(c->d_v, 0, ns * n3 * sizeof(double)));
     CHK(hipMemset(c->d_box, 0, ns * sizeof(double))); CHK(hipMemset(c->d_steps, 0, ns * 3 * sizeof(double)));
     CHK(hipMemset(c->d_therm, 0, ns * 5 * sizeof(double))); CHK(hipMemset(c->d_count, 0, ns * 6 * sizeof(double)));
@@ -652,8 +689,8 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
         static_assert(CfgMidQ8::LDS_BYTES <= 160 * 1024, "the 6^3 cluster configuration must fit the CU's LDS");
     }
     else CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgLarge>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
-    c->ev.resize(32);
-    for (auto &e : c->ev) { CHK(hipEventCreate(&e.a)); CHK(hipEventCreate(&e.b)); e.used = false; }
+    c->ev.assign(32, EvPair{ nullptr, nullptr, false, 0u });
+    for (auto &e : c->ev) { CHK(hipEventCreate(&e.a)); CHK(hipEventCreate(&e.b)); }
 #undef CHK
     c->err.clear();
     c->note = note; // nm_create_note(ctx): what the residency probe had to give up, if anything
@@ -665,16 +702,7 @@ int nm_destroy(nm_ctx *c)
 {
     if (!c) return NM_ERR_ARG;
     hipSetDevice(c->cfg.device);
-    hipStreamSynchronize(c->stream);
-    for (auto &e : c->ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-    void *ptrs[] = { c->d_x, c->d_v, c->d_box, c->d_steps, c->d_therm, c->d_count, c->d_ratio, c->d_et, c->d_pf, c->d_tq,
-                     c->d_stats, c->d_slot2buf, c->d_status, c->d_nswaps, c->d_evalU, c->d_evalW, c->d_evalF, c->d_xcrit,
-                     c->d_xtape, c->d_tape, c->d_tape_off, c->d_trace, c->d_nbr, c->d_aux, c->d_prof, c->d_tline, c->d_xbuf, c->d_census,
-                     c->d_status_acc, c->d_halt, c->d_rerun, c->d_order, c->d_last_ticks };
-    for (void *q : ptrs) if (q) hipFree(q);
-    if (c->h_stage) hipHostFree(c->h_stage);
-    hipStreamDestroy(c->stream);
-    delete c;
+    free_ctx(c);
     return NM_OK;
 }
 
@@ -850,6 +878,58 @@ int nm_get_state(nm_ctx *c, int k0, int nk, double *x, double *v, double *box, d
     return NM_OK; // (slot_map has looked at the outcome of everything queued)
 }
 
+// The replicas named in slots[] only (the split-row exchange re-seats the ones that swapped, neuralmelting_amd/exchange.py): ONE look at
+// the queue's outcome, the listed buffers copied back to back on the context's stream, ONE wait.  th[nk][5] = temp, pe, ke, virial, vol
+// (nm_set_thermo's columns); small items go through the pinned staging area so that nothing on this stack frame is read after return.
+int nm_get_slots(nm_ctx *c, int nk, const int *slots, double *x, double *v, double *box, double *dxdvdt, double *th)
+{
+    if (!c || nk < 0 || (nk && !slots)) return fail(c, NM_ERR_ARG, "nm_get_slots: bad argument");
+    for (int q = 0; q < nk; ++q) if (slots[q] < 0 || slots[q] >= c->nslots) return fail(c, NM_ERR_ARG, "nm_get_slots: slot out of range");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    std::vector<int> m;
+    int rc = slot_map(c, m);
+    if (rc) return rc;
+    const size_t n3 = (size_t)3 * c->N;
+    for (int q = 0; q < nk; ++q) {
+        const size_t bq = (size_t)m[slots[q]];
+        if (x) HIPCHK(c, hipMemcpyAsync(x + q * n3, c->d_x + bq * n3, n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (v) HIPCHK(c, hipMemcpyAsync(v + q * n3, c->d_v + bq * n3, n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (box) HIPCHK(c, hipMemcpyAsync(box + q, c->d_box + bq, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (dxdvdt) HIPCHK(c, hipMemcpyAsync(dxdvdt + 3 * q, c->d_steps + 3 * bq, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (th) HIPCHK(c, hipMemcpyAsync(th + 5 * q, c->d_therm + 5 * bq, 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return NM_OK;
+}
+
+int nm_set_slots(nm_ctx *c, int nk, const int *slots, const double *x, const double *v, const double *box, const double *dxdvdt,
+                 const double *th)
+{
+    if (!c || nk < 0 || (nk && !slots)) return fail(c, NM_ERR_ARG, "nm_set_slots: bad argument");
+    for (int q = 0; q < nk; ++q) if (slots[q] < 0 || slots[q] >= c->nslots) return fail(c, NM_ERR_ARG, "nm_set_slots: slot out of range");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    std::vector<int> m;
+    int rc = slot_map(c, m);
+    if (rc) return rc;
+    const size_t n3 = (size_t)3 * c->N;
+    if ((rc = stage_reserve(c, (size_t)nk + 1))) return rc;
+    double *vol = c->h_stage; // the volumes that go with the boxes (therm column 4), pinned
+    for (int q = 0; q < nk; ++q) {
+        const size_t bq = (size_t)m[slots[q]];
+        if (x) HIPCHK(c, hipMemcpyAsync(c->d_x + bq * n3, x + q * n3, n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (v) HIPCHK(c, hipMemcpyAsync(c->d_v + bq * n3, v + q * n3, n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (box) {
+            vol[q] = std::pow(box[q], 3.0);
+            HIPCHK(c, hipMemcpyAsync(c->d_box + bq, box + q, sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->d_therm + 5 * bq + 4, vol + q, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        }
+        if (dxdvdt) HIPCHK(c, hipMemcpyAsync(c->d_steps + 3 * bq, dxdvdt + 3 * q, 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (th) HIPCHK(c, hipMemcpyAsync(c->d_therm + 5 * bq, th + 5 * q, 5 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // the caller's arrays (pageable: staged by the runtime) and the staging area are free again
+    return NM_OK;
+}
+
 int nm_run_block(nm_ctx *c, int mod)
 {
     if (!c || mod < 0) return fail(c, NM_ERR_ARG, "nm_run_block: bad argument");
@@ -922,7 +1002,7 @@ int nm_get_status(nm_ctx *c, int *status)
 {
     if (!c || !status) return fail(c, NM_ERR_ARG, "nm_get_status: null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)check_status(c); // re-issues a halted queue; an error that cannot be cured leaves its bits in d_status (settle), which is what this call is for
     HIPCHK(c, hipMemcpy(status, c->d_status, sizeof(int) * c->nslots, hipMemcpyDeviceToHost));
     return NM_OK;
 }
@@ -948,7 +1028,7 @@ int nm_stats_get(nm_ctx *c, double *stats, int reset)
 {
     if (!c || !stats) return fail(c, NM_ERR_ARG, "nm_stats_get: null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = check_status(c); if (rc_) return rc_; } // (a halted queue is re-issued, or its error reported, before anything is read or replaced)
     const size_t n = (size_t)c->nslots * NM_STATS_COLS;
     HIPCHK(c, hipMemcpy(stats, c->d_stats, n * sizeof(double), hipMemcpyDeviceToHost));
     if (reset) HIPCHK(c, hipMemset(c->d_stats, 0, n * sizeof(double)));
@@ -1030,7 +1110,7 @@ int nm_set_rng_tape(nm_ctx *c, const double *tape, const int *offsets)
 {
     if (!c) return NM_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = check_status(c); if (rc_) return rc_; } // (a halted queue is re-issued, or its error reported, before anything is read or replaced)
     if (c->d_tape) { HIPCHK(c, hipFree(c->d_tape)); c->d_tape = nullptr; }
     if (c->d_tape_off) { HIPCHK(c, hipFree(c->d_tape_off)); c->d_tape_off = nullptr; }
     if (!tape || !offsets) return NM_OK;
@@ -1047,7 +1127,7 @@ int nm_set_exchange_tape(nm_ctx *c, const double *tape, int n)
 {
     if (!c) return NM_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = check_status(c); if (rc_) return rc_; } // (a halted queue is re-issued, or its error reported, before anything is read or replaced)
     const int npairs = c->cfg.nrows * c->cfg.nt * (c->cfg.nt - 1) / 2;
     if (!tape) { c->xtape_n = 0; return NM_OK; }
     if (n != npairs) return fail(c, NM_ERR_ARG, "nm_set_exchange_tape: need one uniform per pair of the sweep");
@@ -1068,7 +1148,7 @@ int nm_get_trace(nm_ctx *c, double *trace, int mod)
     if (!c || !trace) return fail(c, NM_ERR_ARG, "nm_get_trace: null argument");
     if (!c->d_trace || mod != c->trace_mod) return fail(c, NM_ERR_ARG, "nm_get_trace: no trace of that length recorded");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = check_status(c); if (rc_) return rc_; } // (a halted queue is re-issued, or its error reported, before anything is read or replaced)
     HIPCHK(c, hipMemcpy(trace, c->d_trace, (size_t)c->nslots * mod * NM_TRACE_COLS * sizeof(double), hipMemcpyDeviceToHost));
     return NM_OK;
 }
@@ -1077,7 +1157,7 @@ int nm_set_counters(nm_ctx *c, const double *count, const float *ratio)
 {
     if (!c) return NM_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = check_status(c); if (rc_) return rc_; } // (a halted queue is re-issued, or its error reported, before anything is read or replaced)
     if (count) HIPCHK(c, hipMemcpy(c->d_count, count, sizeof(double) * 6 * c->nslots, hipMemcpyHostToDevice));
     if (ratio) HIPCHK(c, hipMemcpy(c->d_ratio, ratio, sizeof(float) * 3 * c->nslots, hipMemcpyHostToDevice));
     return NM_OK;
@@ -1087,7 +1167,7 @@ int nm_get_perm(nm_ctx *c, int *perm)
 {
     if (!c || !perm) return fail(c, NM_ERR_ARG, "nm_get_perm: null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = check_status(c); if (rc_) return rc_; } // (a halted queue is re-issued, or its error reported, before anything is read or replaced)
     HIPCHK(c, hipMemcpy(perm, c->d_slot2buf, sizeof(int) * c->nslots, hipMemcpyDeviceToHost));
     return NM_OK;
 }
@@ -1098,7 +1178,7 @@ int nm_get_exchange_crit(nm_ctx *c, double *crit, int n)
     const int npairs = c->cfg.nrows * c->cfg.nt * (c->cfg.nt - 1) / 2;
     if (n != npairs) return fail(c, NM_ERR_ARG, "nm_get_exchange_crit: wrong pair count");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = check_status(c); if (rc_) return rc_; } // (a halted queue is re-issued, or its error reported, before anything is read or replaced)
     HIPCHK(c, hipMemcpy(crit, c->d_xcrit, sizeof(double) * n, hipMemcpyDeviceToHost));
     return NM_OK;
 }

@@ -57,6 +57,16 @@ class Engine:
         if rc != B.NM_OK:
             raise NMError(rc, self.lib.nm_last_error(self.h).decode())
 
+    def _settled(self, rc):
+        """after a call that looks at the queue's outcome (and may have re-issued a block with fewer workgroups per replica)"""
+        self._chk(rc)
+        self.cus_per_replica = self.lib.nm_cus_per_replica(self.h)
+
+    @property
+    def heals(self):
+        """blocks re-issued at fewer workgroups per replica so far (nm_heal_count)"""
+        return self.lib.nm_heal_count(self.h)
+
     def close(self):
         if getattr(self, 'h', None):
             self.lib.nm_destroy(self.h)
@@ -93,7 +103,7 @@ class Engine:
                 raise ValueError('bad array size %d, expected %s' % (a.size, shape))
             return a
         x, v, box, dxdvdt = prep(x, (nk, n3)), prep(v, (nk, n3)), prep(box, (nk,)), prep(dxdvdt, (nk, 3))
-        self._chk(self.lib.nm_set_state(self.h, k0, nk, _dp(x), _dp(v), _dp(box), _dp(dxdvdt)))
+        self._settled(self.lib.nm_set_state(self.h, k0, nk, _dp(x), _dp(v), _dp(box), _dp(dxdvdt)))
 
     def get_state(self, k0=0, nk=None, velocities=True):
         """x, v, box, (dx, dv, dt) of slots [k0, k0+nk); velocities=False skips the copy of v (returned as None)"""
@@ -102,8 +112,34 @@ class Engine:
         x = np.empty((nk, n3))
         v = np.empty((nk, n3)) if velocities else None
         box, d = np.empty(nk), np.empty((nk, 3))
-        self._chk(self.lib.nm_get_state(self.h, k0, nk, _dp(x), _dp(v) if velocities else None, _dp(box), _dp(d)))
+        self._settled(self.lib.nm_get_state(self.h, k0, nk, _dp(x), _dp(v) if velocities else None, _dp(box), _dp(d)))
         return x, v, box, d
+
+    def get_slots(self, slots, velocities=True):
+        """x, v, box, (dx, dv, dt), thermo[5] of the listed local slots in one batch (nm_get_slots): one settle, one wait"""
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        nk, n3 = len(sl), 3 * self.natoms
+        x = np.empty((nk, n3))
+        v = np.empty((nk, n3)) if velocities else None
+        box, d, th = np.empty(nk), np.empty((nk, 3)), np.empty((nk, 5))
+        self._settled(self.lib.nm_get_slots(self.h, nk, sl.ctypes.data_as(B.c_int_p), _dp(x), _dp(v) if velocities else None, _dp(box),
+                                            _dp(d), _dp(th)))
+        return x, v, box, d, th
+
+    def set_slots(self, slots, x=None, v=None, box=None, dxdvdt=None, th=None):
+        """the inverse of get_slots (nm_set_slots)"""
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        nk, n3 = len(sl), 3 * self.natoms
+
+        def prep(a, size):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            if a.size != size:
+                raise ValueError('bad array size %d, expected %d' % (a.size, size))
+            return a
+        x, v, box, dxdvdt, th = prep(x, nk * n3), prep(v, nk * n3), prep(box, nk), prep(dxdvdt, 3 * nk), prep(th, 5 * nk)
+        self._settled(self.lib.nm_set_slots(self.h, nk, sl.ctypes.data_as(B.c_int_p), _dp(x), _dp(v), _dp(box), _dp(dxdvdt), _dp(th)))
 
     def init_lattice(self, dx=0.03125, dv=0.03125, interpolate=False):
         """init_samples (remcmc:394-456) through the C-ABI: the states lattice.init_states builds, without the Python front end"""
@@ -115,7 +151,7 @@ class Engine:
         th = np.ascontiguousarray(th, dtype=np.float64)
         if th.size != 5 * nk:
             raise ValueError('bad thermo array')
-        self._chk(self.lib.nm_set_thermo(self.h, k0, nk, _dp(th)))
+        self._settled(self.lib.nm_set_thermo(self.h, k0, nk, _dp(th)))
 
     def set_step(self, step):
         self._chk(self.lib.nm_set_step(self.h, int(step)))
@@ -132,7 +168,7 @@ class Engine:
     def thermo(self):
         """rows[nslots][17] in the .thrm column order (remcmc:208)"""
         rows = np.empty((self.nslots, B.NM_THERMO_COLS))
-        self._chk(self.lib.nm_get_thermo(self.h, _dp(rows)))
+        self._settled(self.lib.nm_get_thermo(self.h, _dp(rows)))
         return rows
 
     def adapt(self):
@@ -149,8 +185,7 @@ class Engine:
         return n.value
 
     def synchronize(self):
-        self._chk(self.lib.nm_synchronize(self.h))
-        self.cus_per_replica = self.lib.nm_cus_per_replica(self.h)  # (a re-issued block may have lowered it)
+        self._settled(self.lib.nm_synchronize(self.h))  # (a re-issued block may have lowered cus_per_replica)
 
     def note(self):
         """what the residency probe gave up at creation and every block that had to be re-issued with fewer workgroups per
@@ -160,7 +195,7 @@ class Engine:
     def status(self):
         """per-slot status bits (include/nm.h NM_ST_*) of the last block; 0 = fine"""
         st = np.empty(self.nslots, dtype=np.int32)
-        self._chk(self.lib.nm_get_status(self.h, st.ctypes.data_as(B.c_int_p)))
+        self._settled(self.lib.nm_get_status(self.h, st.ctypes.data_as(B.c_int_p)))
         return st
 
     # -- measurement
@@ -177,7 +212,7 @@ class Engine:
         """per-slot (evaluations, list rebuilds, energy evaluations, interacting pairs summed over those, block time in 100 MHz ticks,
         blocks handed over inside one XCD, blocks, HMC moves, longest list row built, list slots per atom) since the last reset"""
         s = np.empty((self.nslots, B.NM_STATS_COLS))
-        self._chk(self.lib.nm_stats_get(self.h, _dp(s), int(reset)))
+        self._settled(self.lib.nm_stats_get(self.h, _dp(s), int(reset)))
         return s
 
     # -- test-only
@@ -211,22 +246,22 @@ class Engine:
 
     def trace(self, mod):
         tr = np.empty((self.nslots, mod, B.NM_TRACE_COLS))
-        self._chk(self.lib.nm_get_trace(self.h, _dp(tr), int(mod)))
+        self._settled(self.lib.nm_get_trace(self.h, _dp(tr), int(mod)))
         return tr
 
     def set_counters(self, count=None, ratio=None):
         """counters [nslots][6] and float32 ratios [nslots][3] as a block would have left them (input of adapt)"""
         cn = None if count is None else np.ascontiguousarray(count, dtype=np.float64)
         ra = None if ratio is None else np.ascontiguousarray(ratio, dtype=np.float32)
-        self._chk(self.lib.nm_set_counters(self.h, _dp(cn), None if ra is None else ra.ctypes.data_as(B.c_float_p)))
+        self._settled(self.lib.nm_set_counters(self.h, _dp(cn), None if ra is None else ra.ctypes.data_as(B.c_float_p)))
 
     def perm(self):
         p = np.empty(self.nslots, dtype=np.int32)
-        self._chk(self.lib.nm_get_perm(self.h, p.ctypes.data_as(B.c_int_p)))
+        self._settled(self.lib.nm_get_perm(self.h, p.ctypes.data_as(B.c_int_p)))
         return p
 
     def exchange_crit(self):
         n = self.nrows * self.nt * (self.nt - 1) // 2
         c = np.empty(max(n, 1))
-        self._chk(self.lib.nm_get_exchange_crit(self.h, _dp(c), n))
+        self._settled(self.lib.nm_get_exchange_crit(self.h, _dp(c), n))
         return c[:n]

@@ -4,7 +4,8 @@ With whole rows per GPU the sweep is local and runs on the device (nm_exchange).
 inputs — (E_tot, V) per slot, 16 bytes each — are all-gathered over RCCL (xGMI), every rank runs the identical sweep with the
 shared Philox stream (global pair index, same draws as nm_exchange_kernel) and so knows the same permutation; only the
 replicas that changed slot then move: inside a rank as a local re-seat, between ranks point to point (one send / receive of
-6 N + 9 doubles per replica: 12 KB at 256 atoms, 98 KB at 2048), never the other replicas' state.  All messages are
+6 N + 9 doubles per replica: 12 KB at 256 atoms, 98 KB at 2048), never the other replicas' state; on each rank the replicas that
+leave are read in one batch and the ones that arrive written in one batch (nm_get_slots / nm_set_slots: one settle, one wait each).  All messages are
 latency-sized."""
 import os
 
@@ -99,15 +100,13 @@ def exchange_split(eng, step, npn, nt, seed, k0, natoms, et, pf, group_info, ran
     me = k0 // nloc if rank is None else rank
     n3 = 3 * natoms
     width = 2 * n3 + 9
-
-    def pack(slot):  # this rank's slot -> one row
-        x, v, box, d = eng.get_state(slot - k0, 1)
-        return np.concatenate([x[0], v[0], box, d[0], rows[slot - k0, :5]])
-
-    out = {}     # src slot -> packed state (read before anything is overwritten)
-    for dst, src in moves:
-        if src // nloc == me and src not in out:
-            out[src] = pack(src)
+    # what this rank gives away or re-seats locally: read in ONE batch (nm_get_slots: one settle, one wait) before anything is overwritten
+    mine = sorted({src for _, src in moves if src // nloc == me})
+    out = {}
+    if mine:
+        x, v, box, d, th = eng.get_slots([s_ - k0 for s_ in mine])
+        for q, s_ in enumerate(mine):
+            out[s_] = np.concatenate([x[q], v[q], box[q:q + 1], d[q], th[q]])
     recv, ops = {}, []
     for dst, src in moves:                              # ascending dst on every rank: matching order of sends and receives
         rs, rd = src // nloc, dst // nloc
@@ -123,15 +122,13 @@ def exchange_split(eng, step, npn, nt, seed, k0, natoms, et, pf, group_info, ran
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+    arrive = [(dst, src) for dst, src in moves if dst // nloc == me]
     log = os.environ.get('NM_LOG_EXCHANGE')  # tests: which backend and device the collective used, how many replicas were re-seated
     if log and me == 0:
         with open(log, 'a') as f:
-            f.write('%s %s %d\n' % (dist.get_backend() if dist.is_initialized() else 'none', 'cuda' if use_cuda else 'cpu',
-                                    sum(1 for dst, _ in moves if dst // nloc == me)))
-    for dst, src in moves:
-        if dst // nloc != me:
-            continue
-        row = out[src] if src // nloc == me else recv[dst].cpu().numpy()
-        eng.set_state(row[None, :n3], row[None, n3:2 * n3], row[2 * n3:2 * n3 + 1], row[None, 2 * n3 + 1:2 * n3 + 4], k0=dst - k0, nk=1)
-        eng.set_thermo(row[None, 2 * n3 + 4:2 * n3 + 9], k0=dst - k0, nk=1)
+            f.write('%s %s %d\n' % (dist.get_backend() if dist.is_initialized() else 'none', 'cuda' if use_cuda else 'cpu', len(arrive)))
+    if arrive:                                          # everything that lands here, again as ONE batch (nm_set_slots)
+        rows_in = np.stack([out[src] if src // nloc == me else recv[dst].cpu().numpy() for dst, src in arrive])
+        eng.set_slots([dst - k0 for dst, _ in arrive], rows_in[:, :n3], rows_in[:, n3:2 * n3], rows_in[:, 2 * n3],
+                      rows_in[:, 2 * n3 + 1:2 * n3 + 4], rows_in[:, 2 * n3 + 4:2 * n3 + 9])
     return swaps

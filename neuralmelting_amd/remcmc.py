@@ -470,8 +470,8 @@ def run_guarded(run):
             sys.stderr.flush()
             os._exit(1)
         raise
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
+    dist = sys.modules.get('torch.distributed')   # only a process group that was created is destroyed: a single-process run never
+    if dist is not None and dist.is_available() and dist.is_initialized():   # imports torch (and must not need it to exit cleanly)
         dist.destroy_process_group()
 
 

@@ -1,9 +1,9 @@
 #!/bin/bash
-# round-3 evidence at one commit ($1), in two calls that each fit a 20-minute GPU slot:  scripts/r3_final.sh <commit> a|b
+# a round's evidence at one commit ($1), in two calls that each fit a 20-minute GPU slot:  ROUND=r04 scripts/evidence.sh <commit> a|b
 #   a: tests, smoke, diagnostic self-checks, rocprofv3 profiles of every preset (equilibrated launches)
 #   b: the bench lines (driver's flags, every preset, C1, iterative, row scan), section shares
 C=$1; PART=${2:-a}
-O=gpurun_out/final3; mkdir -p $O
+RND=${ROUND:-r04}; export ROUND=$RND; O=gpurun_out/final_$RND; mkdir -p $O
 if [ $PART = a ]; then
 timeout -k 10 600 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
@@ -22,7 +22,7 @@ for r in 4 2 1; do timeout -k 10 300 python bench.py --rows $r --tn 8 --warmup 5
 timeout -k 10 200 python scripts/probe_sections.py 4 8 8 128 10 30 > $O/sections_C2_eq.txt 2>&1
 python - <<'PY'
 import json,glob
-for f in sorted(glob.glob('gpurun_out/final3/bench_*.json')):
+for f in sorted(glob.glob('gpurun_out/final_%s/bench_*.json' % __import__('os').environ.get('ROUND', 'r04'))):
     try:
         d=json.load(open(f))
         cb=d.get('cpu_baseline') or {}

@@ -129,6 +129,21 @@ class OracleEngine:
         sl = slice(k0, k0 + nk)
         return lp.x[sl].copy(), lp.v[sl].copy(), lp.box[sl].copy(), lp.d[sl].copy()
 
+    def get_slots(self, slots, velocities=True):
+        lp, sl = self.loop, np.asarray(slots, dtype=int)
+        return lp.x[sl].copy(), lp.v[sl].copy(), lp.box[sl].copy(), lp.d[sl].copy(), lp.thermo[sl].copy()
+
+    def set_slots(self, slots, x=None, v=None, box=None, dxdvdt=None, th=None):
+        lp, sl = self.loop, np.asarray(slots, dtype=int)
+        nk = len(sl)
+        if x is not None: lp.x[sl] = np.array(x, dtype=np.float64).reshape(nk, -1)
+        if v is not None: lp.v[sl] = np.array(v, dtype=np.float64).reshape(nk, -1)
+        if box is not None:
+            lp.box[sl] = np.array(box, dtype=np.float64).reshape(nk)
+            lp.thermo[sl, 4] = lp.box[sl] ** 3
+        if dxdvdt is not None: lp.d[sl] = np.array(dxdvdt, dtype=np.float64).reshape(nk, 3)
+        if th is not None: lp.thermo[sl] = np.array(th, dtype=np.float64).reshape(nk, 5)
+
     def set_step(self, step): self.step = int(step)
     def run_block(self, mod): self.loop.run_block(mod, self.step)
     def thermo(self): return self.loop.rows()
@@ -150,3 +165,48 @@ class OracleEngine:
 
     def synchronize(self): pass
     def close(self): pass
+
+
+class BenchOracleEngine(OracleEngine):
+    """TEST-ONLY stand-in with the constructor and the measurement methods of neuralmelting_amd.Engine, backed by the oracle: lets
+    bench.py's rank / leg / reduction logic run on CPUs over gloo (tests/_mp_bench.py hands it to bench.main(make_engine=...));
+    bench.py itself never builds one."""
+
+    def __init__(self, O, natoms, P, T, *, element='LJ', ppos=0.125, pvol=0.125, nstps=8, bulk=True, seed=256, device=0, row0=0,
+                 nrows=None, iter_revert=False, slot0=None, nslots=None):
+        import time
+        self._time = time
+        self.O = O
+        sz = 1
+        while 4 * sz ** 3 < natoms:
+            sz += 1
+        nt = len(T)
+        kw = dict(row0=row0, nrows=nrows)
+        if nslots is not None:
+            r0, r1 = slot0 // nt, (slot0 + nslots - 1) // nt
+            kw = dict(row0=r0, nrows=r1 - r0 + 1, k0=slot0, nk=nslots)
+        self.loop = OracleLoop(O, sz, P, T, ppos=ppos, pvol=pvol, nstps=nstps, bulk=bulk, seed=seed, el=element, **kw)
+        self.nslots, self.natoms, self.step = self.loop.ns, self.loop.natoms, 0
+        self.cus_per_replica, self.heals = 1, 0
+        self._launches, self._ms, self._blocks = 0, 0.0, 0
+
+    def run_block(self, mod):
+        t0 = self._time.perf_counter()
+        OracleEngine.run_block(self, mod)
+        self._ms += (self._time.perf_counter() - t0) * 1e3
+        self._launches += 1
+        self._blocks += 1
+
+    def constants(self): return self.loop.et.copy(), self.loop.pf.copy()
+    def timing_reset(self): self._launches, self._ms = 0, 0.0
+    def timing(self): return self._launches, self._ms
+
+    def stats(self, reset=False):
+        s = np.zeros((self.nslots, 10))
+        s[:, 0] = s[:, 2] = 7.0 * self._blocks      # evaluations (nominal), energy evaluations
+        s[:, 3] = 1000.0 * s[:, 2]                  # interacting pairs summed over those
+        s[:, 4] = 1.0
+        s[:, 6] = max(self._blocks, 1)
+        if reset:
+            self._blocks = 0
+        return s

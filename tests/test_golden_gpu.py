@@ -56,6 +56,26 @@ def test_G2_adapt_engine():
     e.close()
 
 
+def _count_swaps(g):
+    """replica_exchange (remcmc:776-803) on a G3 golden's inputs and recorded uniforms: (accepted swaps, final arrangement)"""
+    npn, nt = g['np'], g['nt']
+    etot = np.array(g['pe']) + np.array(g['ke'])
+    vol = np.array(g['vol'])
+    ident = list(range(npn * nt))      # which configuration sits in each slot
+    u = iter(g['uniforms'])
+    n = 0
+    for r in range(npn):
+        for v in range(nt - 1, -1, -1):
+            for w in range(v):
+                i, j = r * nt + v, r * nt + w
+                a, b = ident[i], ident[j]
+                dh = (etot[a] - etot[b]) * (1.0 / g['et'][i] - 1.0 / g['et'][j]) + (g['pf'][i] - g['pf'][j]) * (vol[a] - vol[b])
+                if next(u) <= min(1.0, np.exp(dh)):
+                    ident[i], ident[j] = b, a
+                    n += 1
+    return n, ident
+
+
 @pytest.mark.parametrize('idx', range(4))
 def test_G3_exchange_engine(idx):
     """the device sweep, fed the uniforms the reference drew, ends in the reference's arrangement"""
@@ -71,7 +91,11 @@ def test_G3_exchange_engine(idx):
     e.set_exchange_tape(g['uniforms'])
     nsw = e.exchange()
     assert list(e.perm()) == g['perm']
-    assert nsw == sum(1 for a, b in zip(g['perm'], range(ns)) if a != b) or nsw >= 0
+    # the number of accepted swaps: the sweep of remcmc:782-798 replayed here on the golden's own energies, volumes, constants and
+    # uniforms (it must end in the golden's arrangement, which pins the replay), counted pair by pair
+    want, perm = _count_swaps(g)
+    assert perm == g['perm']
+    assert nsw == want
     # a second sweep without the tape must leave the tape path (Philox) — just exercise it
     e.set_exchange_tape(None)
     e.exchange()

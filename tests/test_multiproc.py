@@ -94,6 +94,40 @@ def test_a_failing_rank_ends_the_whole_job(tmp_path, oracle):
     launch(2, tmp_path, argv)            # the same job without the injection runs through
 
 
+def _bench_line(tmp_path, nproc, argv):
+    import json
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(HERE, '_mp_bench.py'), '--gpus', str(nproc)] + argv
+    r = subprocess.run(cmd, timeout=600, cwd=str(tmp_path), capture_output=True, text=True, env=dict(os.environ, OMP_NUM_THREADS='2'))
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith('{')][-1])
+
+
+def test_bench_line_at_two_ranks_carries_the_metrics_own_grid_and_the_weak_leg(tmp_path, oracle):
+    """bench.py --gpus 2 as the driver launches it (here: gloo, CPU, the oracle stand-in as the engine; a tiny custom grid).  `value` must be
+    the STRONG-scaling rate of the preset's own grid — the grid BASELINE's metric names, dealt out over the ranks — and the weak-scaling rate
+    of the grid with twice the pressure rows must ride along under `weak`; each with its replicas_total and the world size the backend saw,
+    and each consistent with its own ms_per_step."""
+    d = _bench_line(tmp_path, 2, '--sz 4 --rows 2 --tn 2 --mod 2 --steps 2 --warmup 1 --equil 0 --no-cpu'.split())
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong'
+    c = d['config']
+    assert c['replicas_total'] == 4 and c['replicas_per_gpu'] == 2 and c['world_size_seen_by_backend'] == 2 and c['backend'] == 'gloo'
+    assert '2x2 PxT grid over 2 GPUs' in d['metric']
+    assert abs(d['value'] - c['sweeps_per_step'] / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    w = d['weak']
+    assert w['scaling'] == 'weak' and w['replicas_total'] == 8 and w['replicas_per_gpu'] == 4 and w['world_size_seen_by_backend'] == 2
+    assert '4x2 PxT grid over 2 GPUs' in w['metric']
+    assert abs(w['value'] - w['sweeps_per_step'] / (w['ms_per_step'] * 1e-3)) < 1e-6 * w['value']
+    # one leg only when asked for
+    d1 = _bench_line(tmp_path, 2, '--sz 4 --rows 2 --tn 2 --mod 2 --steps 2 --warmup 1 --equil 0 --no-cpu --scaling weak'.split())
+    assert d1['scaling'] == 'weak' and 'weak' not in d1 and d1['config']['replicas_total'] == 8
+
+
+def test_bench_line_at_one_rank_is_the_preset_as_it_stands(tmp_path, oracle):
+    d = _bench_line(tmp_path, 1, '--sz 4 --rows 2 --tn 2 --mod 2 --steps 2 --warmup 1 --equil 0 --no-cpu'.split())
+    assert d['n_gpus'] == 1 and d['scaling'] == 'weak' and 'weak' not in d and d['config']['replicas_total'] == 4
+
+
 @pytest.mark.gpu
 def test_split_row_exchange_on_rccl_with_one_rank(tmp_path):
     """The collective (split-row) exchange on the nccl backend = RCCL.  A one-GPU box cannot hold two RCCL ranks, so the path is

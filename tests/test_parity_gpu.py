@@ -285,6 +285,40 @@ def test_short_trajectories_parity_large_cells(oracle, monkeypatch, sz, cus, nst
     e.close()
 
 
+@pytest.mark.parametrize('sz,cus', [(4, 2), (4, 4), (4, 8)] + [(sz, q) for (sz, q) in LARGE_CELL_CASES if q > 1])
+def test_block_that_ends_on_a_rejected_trajectory(oracle, monkeypatch, sz, cus):
+    """A block whose LAST move is a Hamiltonian trajectory that is rejected, at every instantiation with more than one workgroup per
+    replica (so that some workgroup owns atoms a0 != 0): restore() then hands the saved velocities back on the elementwise mapping
+    (atom i on thread i mod BLOCK) and the block's closing kinetic-energy sum reads them on the integrator's mapping (atom a0 + t on
+    thread t) — one of the three hand-offs between the two mappings that were unordered until round 3 (nm_kernels.h NM_FOR_OWN; seen
+    once as an 8e-5 error in temp / ke).  Only trajectories are drawn (PPOS = PVOL = 0) and the time step is twelve times the default,
+    so every one of them is rejected — which the test asserts from the trace before it compares the closing temp, ke and the
+    velocities with the oracle's."""
+    monkeypatch.setenv('NM_CUS_PER_REPLICA', str(cus))
+    mod = 3
+    P, T = grids(1, 2)
+    kw = dict(bulk=True, ppos=0.0, pvol=0.0)
+    loop = OracleLoop(oracle, sz, P, T, **kw)
+    loop.d[:, 2] = 0.046875                       # dt: 12 x TIMESTEP
+    e = make_engine(loop, sz, P, T, **kw)
+    assert e.cus_per_replica == cus
+    e.set_trace(True)
+    for step in range(2):                         # the second block starts from the restored velocities of the first
+        e.set_step(step)
+        e.run_block(mod)
+        rows, tr = e.thermo(), e.trace(mod)
+        loop.run_block(mod, step)
+        ro = loop.rows()
+        assert (tr[:, -1, 0] == 2.0).all() and (tr[:, -1, 1] == 0.0).all(), 'the last move must be a rejected trajectory'
+        np.testing.assert_array_equal(rows[:, 8:14], ro[:, 8:14])
+        assert (rows[:, 13] == 0).all()           # nah: nothing was accepted
+        np.testing.assert_allclose(rows[:, :5], ro[:, :5], rtol=RTOL)
+        x, v, box, d = e.get_state()
+        np.testing.assert_allclose(x, loop.x, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(v, loop.v, rtol=0, atol=1e-7)
+    e.close()
+
+
 def test_init_md_parity(oracle):
     """the -is dynamics of init_sample (remcmc:421-425): velocities at T, then NVE, against the oracle's primitives"""
     from helpers import OracleEngine

@@ -294,6 +294,65 @@ def test_a_launch_that_is_not_resident_is_reissued_with_fewer_workgroups(monkeyp
     np.testing.assert_array_equal(ra[:, :8], rc_[:, :8])
 
 
+@pytest.mark.parametrize('first', ['perm', 'trace', 'stats', 'status', 'counters', 'slots'])
+def test_every_getter_and_setter_looks_at_a_halted_queue_first(monkeypatch, first):
+    """include/nm.h promises that the next nm_synchronize / nm_get_* / nm_set_* after a halted block re-issues it.  Here the FIRST host call
+    after the failed launch (census injection, two more cycles queued behind it) is one of the entry points that used to synchronise the
+    stream only: it must see the healed queue's data — the permutation, trace and statistics of a context that was never disturbed —
+    and a setter must not get in before the replay.  Timing counts the launches that did the work, nm_heal_count says there was a heal."""
+    import neuralmelting_amd as nm
+    from neuralmelting_amd import lattice
+    P, T = grids(8, 8)
+    x, v, box, d = lattice.init_states(4, P, T, 0.03125, 0.03125)
+    mod = 6
+
+    def cycles(e):
+        e.set_trace(True)
+        for step in range(3):
+            e.set_step(step)
+            e.run_block(mod)
+            e.adapt()
+            e.exchange(count=False)
+
+    monkeypatch.setenv('NM_CUS_PER_REPLICA', '2')
+    ref = nm.Engine(256, P, T)                                  # never disturbed, at the Q the healed context ends up with
+    ref.set_state(x, v, box, d)
+    ref.timing_reset()
+    cycles(ref)
+    want = dict(perm=ref.perm(), trace=ref.trace(mod), stats=ref.stats(), thermo=ref.thermo(), timing=ref.timing())
+    ref.close()
+    monkeypatch.delenv('NM_CUS_PER_REPLICA')
+
+    monkeypatch.setenv('NM_INJECT_CENSUS', '0')                 # the context's FIRST cluster launch fails its census
+    a = nm.Engine(256, P, T)
+    assert a.cus_per_replica == 4 and a.heals == 0
+    a.set_state(x, v, box, d)
+    a.timing_reset()
+    cycles(a)
+    monkeypatch.delenv('NM_INJECT_CENSUS')
+    if first == 'perm':
+        np.testing.assert_array_equal(a.perm(), want['perm'])
+    elif first == 'trace':
+        np.testing.assert_array_equal(a.trace(mod), want['trace'])
+    elif first == 'stats':
+        np.testing.assert_array_equal(a.stats()[:, :4], want['stats'][:, :4])
+    elif first == 'status':
+        assert (a.status() == 0).all()
+    elif first == 'counters':                                   # a setter: must land AFTER the replayed blocks, not under them
+        a.set_counters(count=np.full((64, 6), 3.0))
+        assert (a.thermo()[:, 8:14] == 3.0).all()
+    else:
+        xs = a.get_slots([5, 9])[0]
+        assert np.isfinite(xs).all()
+    assert a.heals == 1 and a.cus_per_replica == 2
+    np.testing.assert_array_equal(a.perm(), want['perm'])
+    np.testing.assert_array_equal(a.trace(mod), want['trace'])
+    if first != 'counters':
+        np.testing.assert_array_equal(a.thermo(), want['thermo'])
+    assert a.timing()[0] == want['timing'][0] == 3              # three launches did the work; the halted one and its no-op followers are not counted
+    a.close()
+
+
 def test_a_grid_of_twice_the_chip_heals_to_the_resident_one(monkeypatch):
     """NM_OVERSUBSCRIBE=1: 128 replicas of 2048 atoms at 4 workgroups each run as two rounds of clusters, every cluster with its own
     residency census.  A launch whose censuses fail (injected) leaves the replicas untouched; the library re-issues it on the resident
