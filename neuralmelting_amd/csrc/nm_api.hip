@@ -78,6 +78,7 @@ struct nm_ctx {
     unsigned long long *d_last_ticks;
     bool use_order; // one workgroup per replica and more replicas than CUs: launch the slowest slots first (nm_order_kernel)
     unsigned int *d_census; // residency census of cluster launches (nm_kernels.h): the grid's counter, then one per cluster
+    unsigned int census_base = 0, census_cbase = 0; // what those counters stand at (they only grow; reset_census zeroes both)
     bool over;              // the grid holds twice the clusters the chip does at once (pick_q)
     // Calls queued on the stream since the host last looked at the outcome (settle): if a block of them stopped because its
     // cluster grid was not resident or a hand-over timed out, nothing after it has run (KParams::halt) and the same calls are
@@ -151,6 +152,7 @@ void fill_params(const nm_ctx *c, KParams &p)
     p.prof = c->d_prof;
     p.cus = c->cus; p.xbuf = c->d_xbuf; p.launch_id = c->launch_id;
     p.census = c->cus > 1 ? c->d_census : nullptr; p.over = (c->cus > 1 && c->over) ? 1 : 0;
+    p.census_base = c->census_base; p.census_cbase = c->census_cbase;
     p.plain_granules = 1;
     if (const char *e = std::getenv("NM_PLAIN_GRANULES")) p.plain_granules = std::atoi(e);
     p.dbg = 0;
@@ -178,21 +180,26 @@ hipError_t launch_block(const nm_ctx *c, const KParams &p)
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    if (p.census) { // the arrival counters of this launch's residency census
-        const hipError_t e = hipMemsetAsync(c->d_census, 0, sizeof(unsigned int) * census_words(c->nslots), c->stream);
-        if (e != hipSuccess) return e;
-    }
     hipLaunchKernelGGL(nm_block_kernel<C>, dim3(nm_grid(c->nslots, c->cus)), dim3(C::BLOCK), C::LDS_BYTES, c->stream, p);
     return hipGetLastError();
 }
 
+// The census counters only grow (KParams::census_base): zero them and the bases.  At creation, around the residency probes, after a
+// census that was given up (its abort bit would fail every later launch) and long before they could wrap.
+hipError_t reset_census(nm_ctx *c)
+{
+    c->census_base = c->census_cbase = 0;
+    return hipMemsetAsync(c->d_census, 0, sizeof(unsigned int) * census_words(c->nslots), c->stream);
+}
+
 template <class C>
-hipError_t launch_probe(const nm_ctx *c, const KParams &p)
+hipError_t launch_probe(const nm_ctx *c, KParams p)
 {
     hipError_t e = hipFuncSetAttribute((const void *)nm_probe_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(c->d_census, 0, sizeof(unsigned int) * census_words(c->nslots), c->stream);
     if (e != hipSuccess) return e;
+    p.census_base = p.census_cbase = 0; // (the probe starts from zeroed counters; pick_q zeroes them again behind it)
     hipLaunchKernelGGL(nm_probe_kernel<C>, dim3(nm_grid(c->nslots, c->cus)), dim3(C::BLOCK), C::LDS_BYTES, c->stream, p);
     return hipGetLastError();
 }
@@ -271,6 +278,14 @@ enum : int { OP_BLOCK = 0, OP_ADAPT = 1, OP_EXCHANGE = 2, OP_MD = 3 };
 // block had to be given up, again by settle()
 int check_status(nm_ctx *c);
 
+// a cluster launch has been queued: where its census leaves the counters
+void census_advance(nm_ctx *c)
+{
+    if (c->cus <= 1) return;
+    if (c->over) c->census_cbase += (unsigned int)c->cus; else c->census_base += nm_grid(c->nslots, c->cus);
+}
+void fill_census(const nm_ctx *c, KParams &p) { p.census_base = c->census_base; p.census_cbase = c->census_cbase; }
+
 int issue_block(nm_ctx *c, int kind, int arg, uint32_t step, int trace, const int *d_mask, bool timed)
 {
     if (c->journal.size() > 4096 && !d_mask) { // a caller that never looks: bound the journal
@@ -306,7 +321,8 @@ int issue_block(nm_ctx *c, int kind, int arg, uint32_t step, int trace, const in
     if (c->cus > 1) ++c->cluster_launches;
     // status[] holds the bits of the LAST launch (status_acc[] everything since the host last looked); a launch that finds the halt
     // word armed does nothing, and the memset in front of it must not wipe the failed block's bits: they are in status_acc[]
-    HIPCHK(c, hipMemsetAsync(c->d_status, 0, sizeof(int) * c->nslots, c->stream));
+    // (status[]: cleared by each slot's writer inside the kernel; census counters: monotonic — no memsets in front of a launch)
+    if (c->cus > 1 && (c->census_base > 0x3F000000u || c->census_cbase > 0x3F000000u)) { HIPCHK(c, reset_census(c)); fill_census(c, p); }
     if (timed) {
         EvPair &e = c->ev[c->ev_next];
         harvest(c, e);
@@ -316,6 +332,7 @@ int issue_block(nm_ctx *c, int kind, int arg, uint32_t step, int trace, const in
         e.used = true; e.launch_id = c->launch_id;
         c->ev_next = (c->ev_next + 1) % (int)c->ev.size();
     } else HIPCHK(c, launch_kind(c, p));
+    census_advance(c);
     c->journal.push_back({ kind, arg, trace, step, c->launch_id });
     return NM_OK;
 }
@@ -331,8 +348,7 @@ int issue_adapt(nm_ctx *c)
 
 int issue_exchange(nm_ctx *c, uint32_t step)
 {
-    HIPCHK(c, hipMemsetAsync(c->d_nswaps, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL(nm_exchange_kernel, dim3((c->cfg.nrows + 63) / 64), dim3(64), 0, c->stream, c->cfg.nrows, c->cfg.nt,
+    hipLaunchKernelGGL(nm_exchange_kernel, dim3(1), dim3(64), 0, c->stream, c->cfg.nrows, c->cfg.nt,
                        c->cfg.row0, c->cfg.seed, step, c->d_slot2buf, c->d_therm, c->d_et, c->d_pf,
                        c->xtape_n ? c->d_xtape : nullptr, c->d_xcrit, c->d_nswaps, c->d_halt);
     HIPCHK(c, hipGetLastError());
@@ -384,6 +400,7 @@ int pick_q(nm_ctx *c, int qmax, std::string &note)
         bool ok = true;
         for (int v : st) ok = ok && !(v & ST_NOT_RESIDENT);
         HIPCHK(c, hipMemset(c->d_status, 0, sizeof(int) * c->nslots));
+        HIPCHK(c, reset_census(c)); // (the probe's arrivals, or its abort bit, must not meet the first block)
         if (ok) return NM_OK;
         char buf[200];
         std::snprintf(buf, sizeof buf, "%d workgroups per replica (%d in all) did not gather on this device; falling back. ", qq, (int)nm_grid(c->nslots, qq));
@@ -450,6 +467,7 @@ int settle(nm_ctx *c)
             std::string why;
             int rc = pick_q(c, q_old / 2, why);
             if (rc) return rc;
+            HIPCHK(c, reset_census(c)); // (the failed launch's census may have left its abort bit)
             if ((rc = alloc_cluster_buffers(c))) return rc;
             std::vector<int> mask((size_t)c->nslots);
             for (int k = 0; k < c->nslots; ++k) mask[k] = st[k] ? 1 : 0;
@@ -1096,8 +1114,8 @@ int nm_eval(nm_ctx *c, double *U, double *W, double *f)
     fill_params(c, p);
     p.eval_only = 1; p.tape = nullptr;
     p.evalU = c->d_evalU; p.evalW = c->d_evalW; p.evalF = f ? c->d_evalF : nullptr;
-    HIPCHK(c, hipMemsetAsync(c->d_status, 0, sizeof(int) * c->nslots, c->stream));
     HIPCHK(c, launch_kind(c, p));
+    census_advance(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const size_t ns = c->nslots;
     HIPCHK(c, hipMemcpy(U, c->d_evalU, ns * sizeof(double), hipMemcpyDeviceToHost));

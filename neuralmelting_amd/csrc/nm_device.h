@@ -51,7 +51,10 @@ struct KParams {
     double *xbuf;                  // [slot][2][XBUF_DOUBLES]: force slices + partial sums exchanged inside a cluster
     uint32_t launch_id;            // distinguishes the granules of successive launches
     int plain_granules;            // 1: clusters found to sit on one XCD hand over through that XCD's L2 (plain stores); 0: always write-through
-    unsigned int *census;          // cluster launches: arrival counter of the grid's workgroups (zeroed before the launch)
+    unsigned int *census;          // cluster launches: arrival counter of the grid's workgroups, then one per cluster.  The counters only ever
+                                   // grow: a launch is complete at census_base + its own count (no memset in front of every launch); the
+                                   // host zeroes them, and the bases, after a census that was given up (abort bit) and before they could wrap
+    unsigned int census_base, census_cbase; // what the grid's counter / every cluster's counter stood at before this launch
     int *status_acc;               // per slot: status bits of every block since the host last looked (status[] holds the last launch's)
     int *halt;                     // launch id of the first block that stopped on an error; later launches do nothing until the host
                                    // has dealt with it (nm_api.hip settle): a failed block never has successors running on its state

@@ -2018,7 +2018,7 @@ __device__ __forceinline__ bool residency_census(const KParams &p, int cluster)
     int *flag = (int *)(nm_lds + C::OFF_RED);
     if (threadIdx.x == 0) {
         unsigned int *const counter = p.over ? p.census + 1 + cluster : p.census;
-        const unsigned int full = p.over ? (unsigned int)p.cus : gridDim.x;
+        const unsigned int full = (p.over ? p.census_cbase + (unsigned int)p.cus : p.census_base + gridDim.x);
         const unsigned int want = p.inj_census ? full + 1u : full; // (injection: a count nobody can complete)
         atomicAdd(counter, 1u);
         const unsigned long long t0 = wall_clock64();
@@ -2092,6 +2092,10 @@ __global__ void __launch_bounds__(C::BLOCK NM_MIN_WAVES) nm_block_kernel(const K
     Replica<C> R(p, slot, qq);
     const bool writer = (tid == 0 && qq == 0); // one workgroup of the cluster writes the replica's results
     const int N = p.N;
+    // status[] holds the bits of the LAST launch that ran: the writer, the only thread that ever reports for this slot, clears it first
+    // (a memset in front of every launch was one more dependent operation on the stream per cycle).  A launch that found the halt word
+    // armed has returned above and leaves the failed block's bits where they are.
+    if (writer && !(p.rerun_mask && !p.rerun_mask[slot])) p.status[slot] = 0;
 
     if (Q > 1 && p.census && !residency_census<C>(p, cluster)) { // nothing has been touched yet
         if (writer) report_status(p, slot, ST_NOT_RESIDENT, true);
@@ -2418,34 +2422,40 @@ __global__ void nm_adapt_kernel(int nslots, const int *slot2buf, double *steps, 
 // replica_exchange (remcmc:776-803): rows are independent, the sweep inside a row is strictly sequential.
 // A swap exchanges entries [0..11] of the two state lists = configuration, thermo scalars and dx,dv,dt; here
 // that is one swap of slot->buffer labels, no coordinate moves.
-__global__ void nm_exchange_kernel(int nrows, int nt, int row0, uint32_t seed, uint32_t step, int *slot2buf,
+__global__ void __launch_bounds__(64) nm_exchange_kernel(int nrows, int nt, int row0, uint32_t seed, uint32_t step, int *slot2buf,
                                    const double *therm, const double *et, const double *pf, const double *tape,
                                    double *crit_out, int *nswaps, const int *halt)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows || (halt && *halt)) return;
+    // ONE wave: rows r = lane, lane + 64, ...; the swap count is summed over the wave and stored (it used to be an atomicAdd onto a
+    // word zeroed by a memset in front of every launch: one more dependent stream operation per cycle)
+    if (halt && *halt) return;
     const int ppr = nt * (nt - 1) / 2;
-    int q = 0, sw = 0;
-    for (int vv = nt - 1; vv >= 0; --vv)
-        for (int w = 0; w < vv; ++w, ++q) {
-            const int i = r * nt + vv, j = r * nt + w;
-            const int bi = slot2buf[i], bj = slot2buf[j];
-            const double de = (therm[5 * bi + 1] + therm[5 * bi + 2]) - (therm[5 * bj + 1] + therm[5 * bj + 2]);
-            const double dvol = therm[5 * bi + 4] - therm[5 * bj + 4];
-            const double dh = de * (1.0 / et[i] - 1.0 / et[j]) + (pf[i] - pf[j]) * dvol;
-            double u;
-            if (tape) u = tape[r * ppr + q];
-            else {
-                uint32_t o[4];
-                philox4x32_10((uint32_t)((row0 + r) * ppr + q), S_EXCH, 0u, step, seed, 0xFFFFFFFFu, o);
-                u = u01(o[0], o[1]);
+    int sw = 0;
+    for (int r = threadIdx.x; r < nrows; r += 64) {
+        int q = 0;
+        for (int vv = nt - 1; vv >= 0; --vv)
+            for (int w = 0; w < vv; ++w, ++q) {
+                const int i = r * nt + vv, j = r * nt + w;
+                const int bi = slot2buf[i], bj = slot2buf[j];
+                const double de = (therm[5 * bi + 1] + therm[5 * bi + 2]) - (therm[5 * bj + 1] + therm[5 * bj + 2]);
+                const double dvol = therm[5 * bi + 4] - therm[5 * bj + 4];
+                const double dh = de * (1.0 / et[i] - 1.0 / et[j]) + (pf[i] - pf[j]) * dvol;
+                double u;
+                if (tape) u = tape[r * ppr + q];
+                else {
+                    uint32_t o[4];
+                    philox4x32_10((uint32_t)((row0 + r) * ppr + q), S_EXCH, 0u, step, seed, 0xFFFFFFFFu, o);
+                    u = u01(o[0], o[1]);
+                }
+                if (crit_out) crit_out[r * ppr + q] = dh;
+                const double e = exp(dh);
+                const double mm = (e != e) ? e : (e < 1.0 ? e : 1.0);
+                if (u <= mm) { slot2buf[i] = bj; slot2buf[j] = bi; ++sw; }
             }
-            if (crit_out) crit_out[r * ppr + q] = dh;
-            const double e = exp(dh);
-            const double mm = (e != e) ? e : (e < 1.0 ? e : 1.0);
-            if (u <= mm) { slot2buf[i] = bj; slot2buf[j] = bi; ++sw; }
-        }
-    if (sw) atomicAdd(nswaps, sw);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sw += __shfl_xor(sw, d, 64);
+    if (threadIdx.x == 0) *nswaps = sw;
 }
 
 } // namespace nm
