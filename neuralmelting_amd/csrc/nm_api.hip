@@ -44,7 +44,10 @@ typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 192, unsigned char, true, true, 0
 typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 256, unsigned char, true, true, 1> CfgSmallSC;
 typedef Cfg<NM_SMALL_BLOCK, 2 * NM_SMALL_TPA, 256, 256, unsigned char, true, true, 1, 128, true, true> CfgSmallSCQ2; // (own rows, two lists)
 typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 256, unsigned char, true, true, 1, 64, true, true> CfgSmallSCQ4;
-typedef Cfg<512, 1, 864, 160, unsigned short, false, true> CfgMid;     // N <= 864: list in HBM/L2, saved copies in LDS (also at 2 workgroups per replica)
+typedef Cfg<512, 1, 864, 160, unsigned short, false, true> CfgMid;     // N <= 864: list in HBM/L2, saved copies in LDS (here: at 2 workgroups per replica)
+// the same at ONE workgroup per replica (more replicas than CUs: the reference's run.sh setting): every pair lies inside the workgroup and
+// is listed once (Cfg::HALF, nm_kernels.h)
+typedef Cfg<512, 1, 864, 160, unsigned short, false, true, 0, 864, true, false, true> CfgMidH;
 // cluster variants: own atoms 216 / 108
 typedef Cfg<512, 2, 864, 160, unsigned short, false, true> CfgMidQ4;
 // 8 workgroups per replica: 108 own atoms, whose list rows (16-bit, 35 KB) fit in LDS once the saved velocities moved to the spill
@@ -220,7 +223,7 @@ hipError_t launch_kind(const nm_ctx *c, const KParams &p)
     case 0:
         if (c->pot == 1) return c->cus == 4 ? launch_block<CfgSmallSCQ4>(c, p) : c->cus == 2 ? launch_block<CfgSmallSCQ2>(c, p) : launch_block<CfgSmallSC>(c, p);
         return c->cus == 8 ? launch_block<CfgSmallQ8>(c, p) : c->cus == 4 ? launch_block<CfgSmallQ4>(c, p) : c->cus == 2 ? launch_block<CfgSmallQ2>(c, p) : launch_block<CfgSmall>(c, p);
-    case 1: return c->cus == 8 ? launch_block<CfgMidQ8>(c, p) : c->cus == 4 ? launch_block<CfgMidQ4>(c, p) : launch_block<CfgMid>(c, p);
+    case 1: return c->cus == 8 ? launch_block<CfgMidQ8>(c, p) : c->cus == 4 ? launch_block<CfgMidQ4>(c, p) : c->cus == 2 ? launch_block<CfgMid>(c, p) : launch_block<CfgMidH>(c, p);
     default: return launch_block<CfgLarge>(c, p);
     }
 }
@@ -231,7 +234,7 @@ int blocks_per_cu_kind(int kind, int pot, int q)
     case 0:
         if (pot == 1) return q == 4 ? blocks_per_cu<CfgSmallSCQ4>() : q == 2 ? blocks_per_cu<CfgSmallSCQ2>() : blocks_per_cu<CfgSmallSC>();
         return q == 8 ? blocks_per_cu<CfgSmallQ8>() : q == 4 ? blocks_per_cu<CfgSmallQ4>() : q == 2 ? blocks_per_cu<CfgSmallQ2>() : blocks_per_cu<CfgSmall>();
-    case 1: return q == 8 ? blocks_per_cu<CfgMidQ8>() : q == 4 ? blocks_per_cu<CfgMidQ4>() : blocks_per_cu<CfgMid>();
+    case 1: return q == 8 ? blocks_per_cu<CfgMidQ8>() : q == 4 ? blocks_per_cu<CfgMidQ4>() : q == 2 ? blocks_per_cu<CfgMid>() : blocks_per_cu<CfgMidH>();
     default: return blocks_per_cu<CfgLarge>();
     }
 }
@@ -242,7 +245,7 @@ hipError_t probe_kind(const nm_ctx *c, const KParams &p)
     case 0:
         if (c->pot == 1) return c->cus == 4 ? launch_probe<CfgSmallSCQ4>(c, p) : c->cus == 2 ? launch_probe<CfgSmallSCQ2>(c, p) : launch_probe<CfgSmallSC>(c, p);
         return c->cus == 8 ? launch_probe<CfgSmallQ8>(c, p) : c->cus == 4 ? launch_probe<CfgSmallQ4>(c, p) : c->cus == 2 ? launch_probe<CfgSmallQ2>(c, p) : launch_probe<CfgSmall>(c, p);
-    case 1: return c->cus == 8 ? launch_probe<CfgMidQ8>(c, p) : c->cus == 4 ? launch_probe<CfgMidQ4>(c, p) : launch_probe<CfgMid>(c, p);
+    case 1: return c->cus == 8 ? launch_probe<CfgMidQ8>(c, p) : c->cus == 4 ? launch_probe<CfgMidQ4>(c, p) : c->cus == 2 ? launch_probe<CfgMid>(c, p) : launch_probe<CfgMidH>(c, p);
     default: return launch_probe<CfgLarge>(c, p);
     }
 }
@@ -702,6 +705,7 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     }
     else if (c->kind == 1) {
         CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgMid>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgMid::LDS_BYTES));
+        CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgMidH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgMidH::LDS_BYTES));
         CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgMidQ4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgMidQ4::LDS_BYTES));
         CHK(hipFuncSetAttribute((const void *)nm_block_kernel<CfgMidQ8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CfgMidQ8::LDS_BYTES));
         static_assert(CfgMidQ8::LDS_BYTES <= 160 * 1024, "the 6^3 cluster configuration must fit the CU's LDS");

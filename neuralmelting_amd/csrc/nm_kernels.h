@@ -25,6 +25,9 @@ namespace nm {
 #ifndef NM_PAIR_W
 #define NM_PAIR_W 2 // listed neighbours a thread works on at once (pair_vec)
 #endif
+#ifndef NM_HALF_LIST
+#define NM_HALF_LIST 1 // one thread per row (lists in HBM/L2): a pair of two atoms of the same workgroup is listed ONCE (Cfg::HALF); 0 = full lists
+#endif
 #ifndef NM_PRIO_SW
 #define NM_PRIO_SW 12 // pair loop over LDS lists: list entry at which the two waves of a SIMD swap priorities (see pair_loop)
 #endif
@@ -104,7 +107,7 @@ template <typename T, size_t OFF> struct ArrSel<false, T, OFF> { using type = Gl
 // constant offset: no address registers are needed for them (with run-time strides the eighteen array bases were
 // spilled to scratch and reloaded inside the pair loop).
 template <int BLOCK_, int TPA_, int NMAX_, int MAXNB_, typename IdxT_, bool LIST_LDS_, bool SAVE_LDS_, int POT_ = 0, int NLIST_ = NMAX_,
-          bool SAVEV_LDS_ = SAVE_LDS_, bool LDS_LIST2_ = false>
+          bool SAVEV_LDS_ = SAVE_LDS_, bool LDS_LIST2_ = false, bool HALF_ = false>
 struct Cfg {
     // LDS_LIST2: an LDS list is kept twice as well (see LIST2 below): the second copy, the reference positions and the row lengths
     // that belong to the list a move started from live in LDS too.  Affordable once a cluster configuration stores only the rows
@@ -119,6 +122,20 @@ struct Cfg {
     static constexpr bool SAVEV_LDS = SAVEV_LDS_;
     static_assert(SAVE_LDS_ || !SAVEV_LDS_, "saved velocities in LDS only together with the saved positions");
     static constexpr int POT = POT_; // 0 = lj/cut 2.5, 1 = Sutton-Chen EAM (two-pass: densities, then forces)
+    // HALF (round 4): the configurations whose lists live in HBM / L2 with one thread per row evaluate a pair of two atoms of the SAME
+    // workgroup once instead of twice.  The row that holds the pair — chosen by a checkerboard rule, (j > i) == ((i + j) even), so that
+    // every row keeps about half of its own-range neighbours whatever its index — adds the force to its own sum and the opposite force
+    // to the partner's entry of the force array.  That addition is an LDS atomic on a 64-bit INTEGER (fixed point, 2^-36 of the force
+    // unit = 1.5e-11, range 3.3e4: Replica::fixed_add): integer sums do not depend on the order in which the waves' atomics land, so
+    // results stay bit-reproducible (an fp64 atomic add would not be).  Pairs with an atom of another workgroup stay in both rows.
+    // Halves the list bytes streamed per evaluation and the pair evaluations of the own range (all of them at one workgroup per replica).
+    // Measured (round 4, same box, sustained rate, half against full lists): 500 atoms at ONE workgroup per replica (the run.sh setting)
+    // +8.6 %; 864 atoms at two per replica -4 %; 2048 atoms at two per replica -9 %.  Where it loses: the pair loop of the larger cells is
+    // bound by the LDS pipe already (64 unrelated atoms per gather instruction), three atomics per entry make 2.4 times the LDS work of an
+    // entry, only the own range's pairs go away (75 % of the entries at two workgroups per replica), and a cluster loses the epilogue that
+    // integrates and publishes a row's atom as soon as its force is known.  So HALF_ is set for the one-workgroup configuration of the
+    // lists in HBM only (CfgMidH, nm_api.hip); -DNM_HALF_LIST=2 builds every one-thread-per-row configuration with half lists for the A/B.
+    static constexpr bool HALF = !LIST_LDS_ && TPA_ == 1 && POT_ == 0 && (NM_HALF_LIST == 2 || (NM_HALF_LIST == 1 && HALF_));
     static constexpr int BLOCK = BLOCK_, TPA = TPA_, NW = BLOCK_ / 64, G = BLOCK_ / TPA_, NMAX = NMAX_, MAXNB = MAXNB_;
     static constexpr bool LIST_LDS = LIST_LDS_, SAVE_LDS = SAVE_LDS_;
     using IdxT = IdxT_;
@@ -651,8 +668,22 @@ struct Replica {
             }
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
+                if constexpr (C::HALF) {
+                    // candidates of the own range: keep j iff (j > i) == ((i + j) even); the atom itself falls out with them.  below(n): bits 0 .. n-1
+                    auto below = [](int n) -> unsigned int { return n <= 0 ? 0u : n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u; };
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int jb = j0 + 32 * half;
+                        const unsigned int own = below(a1 - jb) & ~below(a0 - jb);
+                        const int d = i[r] - jb; // bit of atom i itself (anywhere: below 0 = every candidate lies above it)
+                        const unsigned int above = ~below(d + 1), under = below(d);
+                        const unsigned int even = ((i[r] + jb) & 1) ? 0xAAAAAAAAu : 0x55555555u; // bits b with i + jb + b even
+                        mm[r][half] &= ~own | (above & even) | (under & ~even);
+                    }
+                } else {
                 if ((unsigned int)(i[r] - j0) < 32u) mm[r][0] &= ~(1u << (i[r] - j0)); // not the atom itself
                 else if ((unsigned int)(i[r] - j0) < 64u) mm[r][1] &= ~(1u << (i[r] - j0 - 32));
+                }
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     unsigned int m = mm[r][half];
@@ -833,7 +864,11 @@ struct Replica {
                     dx -= L * rint(dx * iL); dy -= L * rint(dy * iL); dz -= L * rint(dz * iL);
                     return dx * dx + dy * dy + dz * dz < rl2;
                 };
-                for (int j = 0; j < N; ++j) n_exact += (j != i && inside(j)) ? 1 : 0;
+                auto listed_here = [&](int j) { // HALF: the row that holds a pair of two own atoms
+                    if (!C::HALF || j < a0 || j >= a1) return true;
+                    return (j > i) == (((i + j) & 1) == 0);
+                };
+                for (int j = 0; j < N; ++j) n_exact += (j != i && listed_here(j) && inside(j)) ? 1 : 0;
                 const int c = cnt[i];
                 for (int r = 0; r < c; ++r) {
                     int j;
@@ -846,7 +881,7 @@ struct Replica {
                     if (atomicAdd(&nm_list_miss, 1u) == 0u) { // the first one: which atom is missing, and how far away it is
                         int jm = -1;
                         for (int j = 0; j < N && jm < 0; ++j) {
-                            if (j == i || !inside(j)) continue;
+                            if (j == i || !listed_here(j) || !inside(j)) continue;
                             bool listed = false;
                             for (int r = 0; r < c; ++r) {
                                 int jj;
@@ -985,6 +1020,103 @@ struct Replica {
         pair_pre<WANT_E, W>(xj, yj, zj, ok, xi, yi, zi, invL, rc2, ax, ay, az, e, w, np);
     }
 
+    // HALF: the force array of the own atoms as 64-bit fixed point while a pair loop runs.  fma(t, scale, 1.5 * 2^52) leaves
+    // round(t * scale) in the low mantissa bits (|t * scale| < 2^51); the difference of the bit patterns is that integer.
+    static constexpr double FIX_SCALE = 68719476736.0 /* 2^36 */, FIX_MAGIC = 6755399441055744.0 /* 1.5 * 2^52 */;
+    __device__ __forceinline__ void fixed_add(unsigned int byte_off, double t, double scale) const
+    {
+        const double y = __builtin_fma(t, scale, FIX_MAGIC);
+        const long long n = __double_as_longlong(y) - __double_as_longlong(FIX_MAGIC);
+        (void)__hip_atomic_fetch_add((long long *)__builtin_assume_aligned(nm_lds + byte_off, 8), n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ void half_begin() // own entries of the force array = 0 (as integers and as doubles); ends with a barrier
+    {
+        NM_FOR_OWN(i) { fx[i] = 0.0; fy[i] = 0.0; fz[i] = 0.0; }
+        __syncthreads();
+    }
+    // behind the pair loop: a barrier (every row's and every partner's addend has landed; nobody reads positions any more), then the
+    // own atoms' entries become doubles again, on the thread that integrates them (NM_FOR_OWN, as every later reader of f[] of the own
+    // atoms does).  final_kick: the energy evaluation that ends a trajectory makes the last half kick here and sums the kinetic energy.
+    __device__ __forceinline__ void half_end(bool final_kick, double dtfm, double &kacc)
+    {
+        __syncthreads();
+        NM_FOR_OWN(i) {
+            const double gx = fixed_get(fx[i]), gy = fixed_get(fy[i]), gz = fixed_get(fz[i]);
+            fx[i] = gx; fy[i] = gy; fz[i] = gz;
+            if (final_kick) {
+                const double ux = __builtin_fma(dtfm, gx, vx[i]), uy = __builtin_fma(dtfm, gy, vy[i]), uz = __builtin_fma(dtfm, gz, vz[i]);
+                vx[i] = ux; vy[i] = uy; vz[i] = uz;
+                kacc += p.mass * (ux * ux + uy * uy + uz * uz);
+            }
+        }
+    }
+    __device__ __forceinline__ double fixed_get(const double &slot) const
+    {
+        return (double)__double_as_longlong(slot) * (1.0 / FIX_SCALE);
+    }
+    // W listed neighbours of row i at once (lists in HBM/L2, j = 8 x the atom index); entries that are atoms of this workgroup
+    // (own8 = 8 a0, ownn8 = 8 (a1 - a0)) stand for the pair in BOTH directions: the opposite force goes to the partner, the pair's energy,
+    // virial and count are taken twice (the caller halves the cluster-wide sums as it does for a full list)
+    // (the neighbours' coordinates are handed in: the caller gathers those of the NEXT trip before it calls this for the current one,
+    //  so that the gathers stand in front of this trip's atomics in the LDS queue, which returns in order — with the gathers behind
+    //  them every trip waited for six atomics to drain before its coordinates arrived: C5 share -11 %, run.sh setting +5 %; round 4)
+    template <bool WANT_E, int W>
+    __device__ __forceinline__ void pair_vec_half(const int (&j)[W], const bool (&ok)[W], const double (&xj)[W], const double (&yj)[W],
+                                                  const double (&zj)[W], double xi, double yi, double zi, double invL,
+                                                  double rc2, double &ax, double &ay, double &az, double &e, double &w, double &np,
+                                                  unsigned int own8, unsigned int ownn8)
+    {
+        double dx[W], dy[W], dz[W], r2[W], y[W], t[W], fp[W];
+        const double mhL = -0.5 * L;
+#pragma unroll
+        for (int q = 0; q < W; ++q) { dx[q] = __builtin_fma(-xj[q], invL, xi); dy[q] = __builtin_fma(-yj[q], invL, yi); dz[q] = __builtin_fma(-zj[q], invL, zi); }
+#pragma unroll
+        for (int q = 0; q < W; ++q) { dx[q] = __builtin_amdgcn_fract(dx[q]); dy[q] = __builtin_amdgcn_fract(dy[q]); dz[q] = __builtin_amdgcn_fract(dz[q]); }
+#pragma unroll
+        for (int q = 0; q < W; ++q) { dx[q] = __builtin_fma(dx[q], L, mhL); dy[q] = __builtin_fma(dy[q], L, mhL); dz[q] = __builtin_fma(dz[q], L, mhL); }
+        bool in[W], own[W];
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            r2[q] = dx[q] * dx[q] + dy[q] * dy[q] + dz[q] * dz[q];
+            in[q] = ok[q] && r2[q] < rc2;
+            own[q] = ((unsigned int)j[q] - own8) < ownn8;
+        }
+#pragma unroll
+        for (int q = 0; q < W; ++q) y[q] = __builtin_amdgcn_rcp(r2[q]);
+#pragma unroll
+        for (int q = 0; q < W; ++q) t[q] = __builtin_fma(-r2[q], y[q], 1.0);
+#pragma unroll
+        for (int q = 0; q < W; ++q) y[q] = __builtin_fma(y[q], t[q], y[q]);
+        if (WANT_E) {
+#pragma unroll
+            for (int q = 0; q < W; ++q) t[q] = __builtin_fma(-r2[q], y[q], 1.0);
+#pragma unroll
+            for (int q = 0; q < W; ++q) y[q] = __builtin_fma(y[q], t[q], y[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < W; ++q) y[q] = in[q] ? y[q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < W; ++q) t[q] = y[q] * y[q] * y[q];
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            fp[q] = t[q] * __builtin_fma(2.0, t[q], -1.0) * y[q]; // (pair_pre's units: 24 for force and virial, 4 for the energy)
+            if (WANT_E) { const double wg = own[q] ? 2.0 : 1.0; e += wg * (t[q] * (t[q] - 1.0)); np += in[q] ? wg : 0.0; w += wg * (r2[q] * fp[q]); }
+        }
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            const double tx = dx[q] * fp[q], ty = dy[q] * fp[q], tz = dz[q] * fp[q];
+            ax += tx; ay += ty; az += tz;
+            // the partner's share, -24 t (the row's own sum is scaled by 24 at its end).  UNCONDITIONAL: an entry beyond the cutoff adds an
+            // exact zero (fp = 0), an atom of another workgroup gets a zero scale (its entry of the force array is not read by anybody).
+            // Guarded by `if (own && in)` the compiler gave every neighbour a basic block of its own and the two neighbours of a trip no
+            // longer overlapped: the half list then ran 8-14 % SLOWER than the full one (run.sh setting, C5 share; round 4).
+            const double sc = own[q] ? -24.0 * FIX_SCALE : 0.0;
+            fixed_add((unsigned int)C::OFF_FRC + (unsigned int)j[q], tx, sc);
+            fixed_add((unsigned int)(C::OFF_FRC + A1) + (unsigned int)j[q], ty, sc);
+            fixed_add((unsigned int)(C::OFF_FRC + 2 * A1) + (unsigned int)j[q], tz, sc);
+        }
+    }
+
     // The two waves that share a SIMD (w and w + NW/2) do not share it evenly: the older one wins every arbitration it is
     // ready for, finishes its rows ~1 us before the other, and the younger one then runs alone below the SIMD's fp64 issue
     // rate.  So in the loops over LDS lists the younger wave holds the higher priority for its first NM_PRIO_SW list entries and
@@ -1051,6 +1183,44 @@ struct Replica {
                     unsigned long long cur[PF], nxt[PF];
 #pragma unroll
                     for (int q = 0; q < PF; ++q) cur[q] = q < mych ? nb64[NM_CHECK_INDEX((size_t)(sub + q * TPA) * NMAX + i, C::NBR_G_ELEMS / 4)] : 0ull;
+                    if constexpr (C::HALF) {
+                        // software pipeline over the trips of two neighbours: indices and coordinates of the next trip are fetched before
+                        // the current one is evaluated (an entry that does not exist reads atom 0 and is masked)
+                        static_assert(TPA == 1 && W == 2 && C::CH == 4, "");
+                        int jn[W]; double xn[W], yn[W], zn[W];
+                        auto fetch = [&](unsigned long long word, int e0) {
+#pragma unroll
+                            for (int r = 0; r < W; ++r) {
+                                jn[r] = (int)((word >> (16 * (e0 + r))) & 0xFFFFull); // 8 x the atom index
+                                xn[r] = *(const double *)((const char *)px.ptr() + jn[r]); yn[r] = *(const double *)((const char *)py.ptr() + jn[r]);
+                                zn[r] = *(const double *)((const char *)pz.ptr() + jn[r]);
+                            }
+                        };
+                        fetch(cur[0], 0);
+                        const unsigned int own8 = 8u * (unsigned int)a0, ownn8 = 8u * (unsigned int)(a1 - a0);
+                        for (int k0 = 0; k0 < mych; k0 += PF) {
+#pragma unroll
+                            for (int q = 0; q < PF; ++q) nxt[q] = (k0 + PF + q) < mych ? nb64[NM_CHECK_INDEX((size_t)(k0 + PF + q) * NMAX + i, C::NBR_G_ELEMS / 4)] : 0ull;
+#pragma unroll
+                            for (int q = 0; q < PF; ++q) {
+                                if (k0 + q < mych) {
+                                    const int first = (k0 + q) * C::CH;
+#pragma unroll
+                                    for (int e0 = 0; e0 < C::CH; e0 += W) {
+                                        int jj[W]; bool ok[W]; double xc[W], yc[W], zc[W];
+#pragma unroll
+                                        for (int r = 0; r < W; ++r) { jj[r] = jn[r]; xc[r] = xn[r]; yc[r] = yn[r]; zc[r] = zn[r]; ok[r] = (first + e0 + r) < c; }
+                                        if (e0 + W < C::CH) fetch(cur[q], e0 + W);
+                                        else if (q + 1 < PF) fetch(cur[q + 1], 0);
+                                        else fetch(nxt[0], 0);
+                                        pair_vec_half<WANT_E, W>(jj, ok, xc, yc, zc, xi, yi, zi, invL, rc2, ax, ay, az, e, w, np, own8, ownn8);
+                                    }
+                                }
+                            }
+#pragma unroll
+                            for (int q = 0; q < PF; ++q) cur[q] = nxt[q];
+                        }
+                    } else
                     for (int k0 = 0; k0 < mych; k0 += PF) {
 #pragma unroll
                         for (int q = 0; q < PF; ++q) nxt[q] = (k0 + PF + q) < mych ? nb64[NM_CHECK_INDEX((size_t)(sub + (k0 + PF + q) * TPA) * NMAX + i, C::NBR_G_ELEMS / 4)] : 0ull;
@@ -1081,6 +1251,17 @@ struct Replica {
             if (WANT_E) { e *= 4.0; w *= 24.0; }
             ax = group_sum(ax); ay = group_sum(ay); az = group_sum(az);
             if (WANT_E) { e = group_sum(e); w = group_sum(w); np = group_sum(np); }
+            if constexpr (C::HALF) {
+                // the row's own sum joins what the partners' rows add to this atom (fixed point, like theirs: every addend of an entry is
+                // an integer, the total does not depend on the order); integration waits for the barrier behind the loop (half_end)
+                if (i < a1) {
+                    eacc += e; wacc += w; nacc += np;
+                    fixed_add((unsigned int)C::OFF_FRC + 8u * (unsigned int)i, ax, FIX_SCALE);
+                    fixed_add((unsigned int)(C::OFF_FRC + A1) + 8u * (unsigned int)i, ay, FIX_SCALE);
+                    fixed_add((unsigned int)(C::OFF_FRC + 2 * A1) + 8u * (unsigned int)i, az, FIX_SCALE);
+                }
+                continue;
+            }
             if (i < a1 && sub == 0) {
                 eacc += e; wacc += w; nacc += np;
                 if (WANT_E && fuse) { // the energy evaluation that ends a trajectory: final_integrate on the spot, kinetic energy along
@@ -1332,7 +1513,8 @@ struct Replica {
     // end is the barrier that publishes the positions AND the rebuild decision: the evaluation that follows starts at once.
     // Requires that no thread of the workgroup still reads positions (the caller's evaluation ended with a barrier).
     // mode 1: one half kick + drift; 3: the pair loop did it already (eval_force): f[] holds the new positions of the own atoms
-    // and they are published.
+    // and they are published; 2 (HALF configurations, whose forces are complete only behind the pair loop's barrier): the two half kicks
+    // around the evaluation that just ended — final_integrate of its step, initial_integrate of the next — and the drift.
     __device__ bool advance_and_share(int mode, double dtfm, double h)
     {
         int timeout = 0, poisoned = 0;
@@ -1342,7 +1524,8 @@ struct Replica {
         NM_FOR_OWN(i) {
             const double gx = fx[i], gy = fy[i], gz = fz[i];
             if (mode == 3) { px[i] = gx; py[i] = gy; pz[i] = gz; continue; }
-            const double ux = __builtin_fma(dtfm, gx, vx[i]), uy = __builtin_fma(dtfm, gy, vy[i]), uz = __builtin_fma(dtfm, gz, vz[i]);
+            double ux = __builtin_fma(dtfm, gx, vx[i]), uy = __builtin_fma(dtfm, gy, vy[i]), uz = __builtin_fma(dtfm, gz, vz[i]);
+            if (mode == 2) { ux = __builtin_fma(dtfm, gx, ux); uy = __builtin_fma(dtfm, gy, uy); uz = __builtin_fma(dtfm, gz, uz); } // (as the fused epilogue)
             vx[i] = ux; vy[i] = uy; vz[i] = uz;
             const double nx = __builtin_fma(h, ux, px[i]), ny = __builtin_fma(h, uy, py[i]), nz = __builtin_fma(h, uz, pz[i]);
             px[i] = nx; py[i] = ny; pz[i] = nz;
@@ -1414,9 +1597,11 @@ struct Replica {
 
         double eacc = 0.0, wacc = 0.0, nacc = 0.0, kacc = 0.0;
         PROF_BEGIN();
+        if constexpr (C::HALF) half_begin();
         if (NM_DBG(16)) { }
         else if constexpr (C::POT == 1) pair_loop_sc<true>(invL, eacc, wacc, nacc, kacc, final_kick, dtfm, 0.0);
         else pair_loop<true>(invL, eacc, wacc, nacc, kacc, final_kick, dtfm, 0.0);
+        if constexpr (C::HALF) half_end(final_kick, dtfm, kacc);
         PROF_END(3);
         TLINE(3);
         PROF_BEGIN();
@@ -1447,6 +1632,7 @@ struct Replica {
         const double invL = bc_invL;
         double eacc = 0.0, wacc = 0.0, nacc = 0.0, kacc = 0.0;
         PROF_BEGIN();
+        if constexpr (C::HALF) half_begin();
         if (NM_DBG(16)) { }
         else if constexpr (C::POT == 1) pair_loop_sc<false>(invL, eacc, wacc, nacc, kacc, true, dtfm, h);
         else pair_loop<false>(invL, eacc, wacc, nacc, kacc, true, dtfm, h);
@@ -1454,6 +1640,8 @@ struct Replica {
         TLINE(3);
         PROF_BEGIN();
         st_evals += 1.0;
+        if constexpr (C::HALF) half_end(false, 0.0, kacc); // its barrier is the one below; the caller integrates (advance_and_share mode 2)
+        else
         __syncthreads(); // nobody reads positions any more: they may be advanced
         PROF_END(4);
         TLINE(4);
@@ -2219,7 +2407,7 @@ __global__ void __launch_bounds__(C::BLOCK NM_MIN_WAVES) nm_block_kernel(const K
                 R.eval_force(pre_need, dtfm_, h_);
                 if (__builtin_amdgcn_readfirstlane(R.status) & fatal) break; // own list overflowed: what the pair loop published is poisoned
                 PROF_BEGIN();
-                pre_need = R.advance_and_share(3, dtfm_, h_);
+                pre_need = R.advance_and_share(C::HALF ? 2 : 3, dtfm_, h_);
                 PROF_END(9);
             }
             have_need = true;

@@ -2,7 +2,7 @@
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ['NM_HIP_LIB'] = os.path.join(ROOT, 'neuralmelting_amd', 'libnm_hip_prof.so')
+os.environ['NM_HIP_LIB'] = os.path.join(ROOT, 'neuralmelting_amd', os.environ.get('NM_PROF_LIB', 'libnm_hip_prof.so'))
 import numpy as np
 import neuralmelting_amd as nm
 from neuralmelting_amd import lattice, _lib
