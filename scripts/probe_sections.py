@@ -12,9 +12,11 @@ NAMES = ['eval:entry barrier', 'eval:list check', 'eval:rebuild', 'eval:pair loo
 
 def main(sz=4, rows=8, tn=8, mod=128, cycles=3, warm=6):
     npn = int(os.environ.get('NP_ALL', rows))
-    P = np.linspace(1, 8, npn, dtype=np.float32); T = np.linspace(.25, 2.5, tn, dtype=np.float32)
-    x, v, box, d = lattice.init_states(sz, P, T, 0.03125, 0.03125, row0=0, nrows=rows)
-    e = nm.Engine(4 * sz ** 3, P, T, row0=0, nrows=rows, bulk=os.environ.get('NM_PROBE_ITER') != '1')  # NM_PROBE_ITER=1: iterative position moves
+    el = os.environ.get('NM_PROBE_EL', 'LJ')   # NM_PROBE_EL=Al: the EAM kernels (BASELINE config 4)
+    P = np.linspace(1, 8, npn, dtype=np.float32)
+    T = np.linspace(.25, 2.5, tn, dtype=np.float32) if el == 'LJ' else np.linspace(256.0, 2560.0, tn, dtype=np.float32)
+    x, v, box, d = lattice.init_states(sz, P, T, 0.03125, 0.03125, el=el, row0=0, nrows=rows)
+    e = nm.Engine(4 * sz ** 3, P, T, element=el, row0=0, nrows=rows, bulk=os.environ.get('NM_PROBE_ITER') != '1')  # NM_PROBE_ITER=1: iterative position moves
     e.set_state(x, v, box, d)
     L = _lib.load()
     L.nm_prof_get.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
