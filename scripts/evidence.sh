@@ -1,7 +1,7 @@
 #!/bin/bash
 # a round's evidence at one commit ($1), in two calls that each fit a 20-minute GPU slot:  ROUND=r04 scripts/evidence.sh <commit> a|b
 #   a: tests, smoke, diagnostic self-checks, rocprofv3 profiles of every preset (equilibrated launches)
-#   b: the bench lines (driver's flags, every preset, C1, iterative, row scan), section shares
+#   b: the bench lines (driver's flags, every preset, C1, iterative, row scan, recording on), section shares
 C=$1; PART=${2:-a}
 RND=${ROUND:-r04}; export ROUND=$RND; O=gpurun_out/final_$RND; mkdir -p $O
 if [ $PART = a ]; then
@@ -19,7 +19,10 @@ NM_OVERSUBSCRIBE=1 timeout -k 10 400 python bench.py --config C5 --no-cpu > $O/b
 timeout -k 10 300 python bench.py --rows 2 --tn 2 > $O/bench_C1.json 2> $O/bench_C1.err; echo "bench C1 rc=$?"
 timeout -k 10 300 python bench.py --iterative --cpu-seconds 4 > $O/bench_C2_iter.json 2> $O/bench_C2_iter.err; echo "bench iter rc=$?"
 for r in 4 2 1; do timeout -k 10 300 python bench.py --rows $r --tn 8 --warmup 5 --steps 20 --no-cpu > $O/bench_C2_rows$r.json 2> $O/bench_C2_rows$r.err; done
+timeout -k 10 300 python bench.py --record --no-cpu > $O/bench_C2_record.json 2> $O/bench_C2_record.err; echo "bench C2 record rc=$?"
+timeout -k 10 400 python bench.py --config C5 --record --no-cpu > $O/bench_C5_record.json 2> $O/bench_C5_record.err; echo "bench C5 record rc=$?"
 timeout -k 10 200 python scripts/probe_sections.py 4 8 8 128 10 30 > $O/sections_C2_eq.txt 2>&1
+timeout -k 10 200 python scripts/probe_sections.py 4 4 8 128 10 30 > $O/sections_C2_Q8_32replicas.txt 2>&1
 python - <<'PY'
 import json,glob
 for f in sorted(glob.glob('gpurun_out/final_%s/bench_*.json' % __import__('os').environ.get('ROUND', 'r04'))):
