@@ -28,6 +28,9 @@ namespace nm {
 #ifndef NM_HALF_LIST
 #define NM_HALF_LIST 1 // one thread per row (lists in HBM/L2): a pair of two atoms of the same workgroup is listed ONCE (Cfg::HALF); 0 = full lists
 #endif
+#ifndef NM_SPREAD
+#define NM_SPREAD 1 // pair loop over LDS lists: the row's epilogue on three lanes, its operands prefetched (0: one lane, as in rounds 1-3)
+#endif
 #ifndef NM_PRIO_SW
 #define NM_PRIO_SW 12 // pair loop over LDS lists: list entry at which the two waves of a SIMD swap priorities (see pair_loop)
 #endif
@@ -1137,13 +1140,23 @@ struct Replica {
         double *xg = xb ? xb + (size_t)(gen & 1) * C::XBUF_DOUBLES : nullptr;
         const int g = tid / TPA, sub = tid - g * TPA;
         const double rc2 = p.rc * p.rc;
+        // SPREAD (round 4): the row's epilogue — integrate, publish, store — is done by three lanes, one component each, instead of
+        // lane 0 doing all three in a row (TPA >= 4; the byte / 16-bit LDS lists)
+        constexpr bool SPREAD = (NM_SPREAD != 0) && TPA >= 4 && !C::HALF;
         for (int i0 = a0; i0 < a1; i0 += G) { // uniform trip count keeps the shuffles below convergent
             const int i = i0 + g;
             double ax = 0.0, ay = 0.0, az = 0.0, e = 0.0, w = 0.0, np = 0.0;
+            [[maybe_unused]] double vpre = 0.0, ppre = 0.0;
             prio_begin();
             if (i < a1) {
                 const double xi = __builtin_fma(px[i], invL, 0.5), yi = __builtin_fma(py[i], invL, 0.5), zi = __builtin_fma(pz[i], invL, 0.5); // (pair_pre)
                 const int c = cnt[i];
+                if constexpr (SPREAD) {
+                    // lanes 0, 1, 2 of the row will integrate the x, y, z component (the epilogue below): what they need of the atom is
+                    // asked for NOW and arrives under the neighbours' arithmetic — read in the epilogue, two dependent LDS round trips
+                    // stood behind every pair loop while the LDS pipe was busy with the other waves' gathers
+                    if (fuse && sub < 3) { vpre = vx.ptr()[sub * NMAX + i]; ppre = px.ptr()[sub * NMAX + i]; }
+                }
                 if constexpr (C::LIST_LDS) {
                     constexpr int W = NM_PAIR_W, PW = C::PW, BITS = 8 * (int)sizeof(IdxT);
                     static_assert(PW % W == 0, "");
@@ -1151,6 +1164,7 @@ struct Replica {
                     const int mine = (c - sub + TPA - 1) / TPA; // neighbours of atom i that this thread handles: slots sub, sub+TPA, ...
                     constexpr int KLAST = MAXNB / TPA - PW;     // first entry of a thread's last list word
                     unsigned long long wn = nb64[(size_t)lrow(i) * TPA + sub];
+                    TLINE(1); // (experiment build: the row's prologue is issued)
                     for (int k0 = 0; k0 < mine; k0 += PW) {     // one conflict-free 8-byte read = PW of them
                         const unsigned long long wd = wn;
                         // the NEXT word is asked for now and looked at PW entries later (unconditionally: clamped to the row's last word) —
@@ -1247,6 +1261,7 @@ struct Replica {
                 }
             }
             prio_end();
+            TLINE(5); // (experiment build: the row's neighbours are through; what follows is the epilogue)
             ax *= 24.0; ay *= 24.0; az *= 24.0; // (pair_pre's units)
             if (WANT_E) { e *= 4.0; w *= 24.0; }
             ax = group_sum(ax); ay = group_sum(ay); az = group_sum(az);
@@ -1259,6 +1274,32 @@ struct Replica {
                     fixed_add((unsigned int)C::OFF_FRC + 8u * (unsigned int)i, ax, FIX_SCALE);
                     fixed_add((unsigned int)(C::OFF_FRC + A1) + 8u * (unsigned int)i, ay, FIX_SCALE);
                     fixed_add((unsigned int)(C::OFF_FRC + 2 * A1) + 8u * (unsigned int)i, az, FIX_SCALE);
+                }
+                continue;
+            }
+            if constexpr (SPREAD) {
+                // the three sums sit in lane 0 of the row (group_sum): y moves to lane 1, z to lane 2 (row_shr), and each of the three
+                // lanes finishes its component with the same arithmetic as the one-lane epilogue below (bit-identical forces, velocities
+                // and positions; the kinetic energy is summed per component instead of per atom)
+                const double sy = dpp_mov<0x111>(ay), sz = dpp_mov<0x112>(az); // (moved by EVERY lane, outside any branch: a DPP read
+                // of a lane that is masked off returns zero)
+                const double ac = sub == 0 ? ax : sub == 1 ? sy : sz;
+                if (i < a1 && sub == 0) { eacc += e; wacc += w; nacc += np; }
+                if (i < a1 && sub < 3) {
+                    const int ci = sub * NMAX + i; // x, y, z follow one another NMAX doubles apart in every array
+                    if (WANT_E && fuse) { // the energy evaluation that ends a trajectory: final_integrate on the spot, kinetic energy along
+                        const double u = __builtin_fma(dtfm, ac, vpre);
+                        vx.ptr()[ci] = u;
+                        kacc += p.mass * (u * u);
+                        fx.ptr()[ci] = ac;
+                    } else if (!WANT_E && fuse) {
+                        double u = __builtin_fma(dtfm, ac, vpre);
+                        u = __builtin_fma(dtfm, ac, u);
+                        vx.ptr()[ci] = u;
+                        const double pn = __builtin_fma(h, u, ppre);
+                        if (Q > 1) put_granule(xg + 2 * (size_t)ci, pn, my_magic());
+                        fx.ptr()[ci] = pn;
+                    } else fx.ptr()[ci] = ac;
                 }
                 continue;
             }
@@ -2092,13 +2133,16 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
     // pass 2: forces (and energy, virial) of this workgroup's atoms.  1/r comes from v_rsq_f64 + two Newton steps (~1 ulp), which
     // gives (a/r)^2 and a/r at once: no separate division and square root.
     const double a1r = sqrt(a2);
+    constexpr bool SPREAD = (NM_SPREAD != 0) && TPA >= 4; // the row's epilogue on three lanes, operands prefetched (see pair_loop)
     for (int i0 = a0; i0 < a1; i0 += G) {
         const int i = i0 + g;
         double ax = 0.0, ay = 0.0, az = 0.0, e = 0.0, w = 0.0, np = 0.0;
+        [[maybe_unused]] double vpre = 0.0, ppre = 0.0;
         prio_begin();
         if (i < a1) {
             const double xi = __builtin_fma(px[i], invL, 0.5), yi = __builtin_fma(py[i], invL, 0.5), zi = __builtin_fma(pz[i], invL, 0.5), isi = rho[i];
             const int c = cnt[i];
+            if constexpr (SPREAD) { if (fuse && sub < 3) { vpre = vx.ptr()[sub * NMAX + i]; ppre = px.ptr()[sub * NMAX + i]; } } // (as pair_loop)
             const int mine = (c - sub + TPA - 1) / TPA;
             unsigned long long wn = nb64[(size_t)lrow(i) * TPA + sub];
             for (int k0 = 0; k0 < mine; k0 += 8) {
@@ -2161,6 +2205,28 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
         prio_end();
         ax = group_sum(ax); ay = group_sum(ay); az = group_sum(az);
         if (WANT_E) { e = group_sum(e); w = group_sum(w); np = group_sum(np); }
+        if constexpr (SPREAD) {
+            const double sy = dpp_mov<0x111>(ay), sz = dpp_mov<0x112>(az); // (every lane, outside any branch)
+            const double ac = sub == 0 ? ax : sub == 1 ? sy : sz;
+            if (i < a1 && sub == 0) { eacc += e; wacc += w; nacc += np; }
+            if (i < a1 && sub < 3) {
+                const int ci = sub * NMAX + i;
+                if (WANT_E && fuse) {
+                    const double u = __builtin_fma(dtfm, ac, vpre);
+                    vx.ptr()[ci] = u;
+                    kacc += p.mass * (u * u);
+                    fx.ptr()[ci] = ac;
+                } else if (!WANT_E && fuse) { // (the densities' exchange took generation gen - 1)
+                    double u = __builtin_fma(dtfm, ac, vpre);
+                    u = __builtin_fma(dtfm, ac, u);
+                    vx.ptr()[ci] = u;
+                    const double pn = __builtin_fma(h, u, ppre);
+                    if (Q > 1) put_granule(xb + (size_t)(gen & 1) * C::XBUF_DOUBLES + 2 * (size_t)ci, pn, my_magic());
+                    fx.ptr()[ci] = pn;
+                } else fx.ptr()[ci] = ac;
+            }
+            continue;
+        }
         if (i < a1 && sub == 0) {
             eacc += e; wacc += w; nacc += np;
             if (WANT_E && fuse) { // the energy evaluation that ends a trajectory: final_integrate on the spot, kinetic energy along

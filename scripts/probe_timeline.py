@@ -7,9 +7,10 @@ import numpy as np
 import neuralmelting_amd as nm
 from neuralmelting_amd import lattice, _lib
 
+ROWS = int(os.environ.get('NM_TL_ROWS', '8'))   # 8 rows x 8 = 64 replicas (Q = 4); 4 rows = 32 replicas (Q = 8)
 P = np.linspace(1, 8, 8, dtype=np.float32); T = np.linspace(.25, 2.5, 8, dtype=np.float32)
-x, v, box, d = lattice.init_states(4, P, T, 0.03125, 0.03125)
-e = nm.Engine(256, P, T, ppos=0.0, pvol=0.0, nstps=16)
+x, v, box, d = lattice.init_states(4, P, T, 0.03125, 0.03125, row0=0, nrows=ROWS)
+e = nm.Engine(256, P, T, ppos=0.0, pvol=0.0, nstps=16, row0=0, nrows=ROWS)
 e.set_state(x, v, box, d)
 for s in range(3):
     e.set_step(s); e.run_block(24); e.adapt()
@@ -33,6 +34,11 @@ print('  pair loop per wave: median %7.0f  max-over-waves %7.0f  min-over-waves 
     np.median((t[:, :, list(ev), 3] - t[:, :, list(ev), 2]) * 10.0),
     np.median(np.max(t[:, :, list(ev), 3] - t[:, :, list(ev), 2], axis=(0, 1)) * 10.0),
     np.median(np.min(t[:, :, list(ev), 3] - t[:, :, list(ev), 2], axis=(0, 1)) * 10.0)))
+d = t[:, :, list(ev), :]
+print('  inside the force-only pair loop, per wave (median / max over waves): prologue issued %5.0f / %5.0f   neighbours %5.0f / %5.0f   epilogue %5.0f / %5.0f' % (
+    np.median((d[..., 1] - d[..., 2]) * 10.0), np.median(np.max(d[..., 1] - d[..., 2], axis=(0, 1)) * 10.0),
+    np.median((d[..., 5] - d[..., 1]) * 10.0), np.median(np.max(d[..., 5] - d[..., 1], axis=(0, 1)) * 10.0),
+    np.median((d[..., 3] - d[..., 5]) * 10.0), np.median(np.max(d[..., 3] - d[..., 5], axis=(0, 1)) * 10.0)))
 print('  pair done -> granules read (per wave)  median %7.0f  max %7.0f' % (
     np.median((t[:, :, list(ev), 5] - t[:, :, list(ev), 3]) * 10.0), np.median(np.max(t[:, :, list(ev), 5] - t[:, :, list(ev), 3], axis=(0, 1)) * 10.0)))
 print('  last pair done -> last exchange done   %7.0f' % np.median(np.array([np.max(t[:, :, k, 4]) - np.max(t[:, :, k, 3]) for k in ev]) * 10.0))
