@@ -32,8 +32,11 @@ namespace nm {
 #define NM_SPREAD 1 // pair loop over LDS lists: the row's epilogue on three lanes, its operands prefetched (0: one lane, as in rounds 1-3)
 #endif
 #ifndef NM_PRIO_SW
-#define NM_PRIO_SW 12 // pair loop over LDS lists: list entry at which the two waves of a SIMD swap priorities (see pair_loop)
+#define NM_PRIO_SW 10 // pair loop over LDS lists: list entry at which the two waves of a SIMD swap priorities (see pair_loop); 12 until
+                      // round 4 (equilibrated C2, same box: 1.415 / 1.420 / 1.409 / 1.403 M sweeps/s at 8 / 10 / 12 / 14; a swap point proportional
+                      // to the row's length — a run-time compare in every trip instead of one the compiler folds — measured 3 % slower)
 #endif
+
 constexpr int NVMAX = 16; // widest block reduction (the 16 raw moments of hmc_velocities)
 
 // Diagnostic build only (-DNM_PROF, never the shipped library): shader-clock stamps per section, summed by lane 0
