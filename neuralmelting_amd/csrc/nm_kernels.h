@@ -31,10 +31,22 @@ namespace nm {
 #ifndef NM_SPREAD
 #define NM_SPREAD 1 // pair loop over LDS lists: the row's epilogue on three lanes, its operands prefetched (0: one lane, as in rounds 1-3)
 #endif
-#ifndef NM_PRIO_SW
-#define NM_PRIO_SW 10 // pair loop over LDS lists: list entry at which the two waves of a SIMD swap priorities (see pair_loop); 12 until
-                      // round 4 (equilibrated C2, same box: 1.415 / 1.420 / 1.409 / 1.403 M sweeps/s at 8 / 10 / 12 / 14; a swap point proportional
-                      // to the row's length — a run-time compare in every trip instead of one the compiler folds — measured 3 % slower)
+// pair loop over LDS lists: list entry at which the two waves of a SIMD swap priorities (see pair_loop), by threads per row — a thread
+// holds (row length) / TPA entries, and the best swap point sits at ~0.6 of them.  Equilibrated, same box (round 4): TPA 8 (C2):
+// 1.415 / 1.420 / 1.409 / 1.403 M sweeps/s at 8 / 10 / 12 / 14 (12 in rounds 2-3); TPA 4 (C3 share): 360 k at 20 vs 354 k at 10 or 12,
+// 354 k at 26.  A swap point proportional to the row's own length — a run-time compare in every trip instead of one the compiler
+// folds — measured 3 % slower.
+#ifndef NM_PRIO_SW16
+#define NM_PRIO_SW16 6
+#endif
+#ifndef NM_PRIO_SW8
+#define NM_PRIO_SW8 10
+#endif
+#ifndef NM_PRIO_SW4
+#define NM_PRIO_SW4 20
+#endif
+#ifndef NM_PRIO_SW2
+#define NM_PRIO_SW2 40
 #endif
 
 constexpr int NVMAX = 16; // widest block reduction (the 16 raw moments of hmc_velocities)
@@ -1128,6 +1140,7 @@ struct Replica {
     // rate.  So in the loops over LDS lists the younger wave holds the higher priority for its first NM_PRIO_SW list entries and
     // the older one after that: both stay in the loop to the end (measured +2.9 % on the 4^3 cluster; either wave favoured
     // throughout: no gain).
+    static constexpr int PRIO_SW = TPA >= 16 ? NM_PRIO_SW16 : TPA >= 8 ? NM_PRIO_SW8 : TPA >= 4 ? NM_PRIO_SW4 : NM_PRIO_SW2;
     __device__ __forceinline__ bool young() const { return (tid >> 6) >= NW / 2; }
     __device__ __forceinline__ void prio_begin() const { if constexpr (C::LIST_LDS) { if (young()) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } }
     __device__ __forceinline__ void prio_swap() const { if constexpr (C::LIST_LDS) { if (young()) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); } }
@@ -1175,7 +1188,7 @@ struct Replica {
                         wn = nb64[((size_t)(min(k0 + PW, KLAST) >> C::LOG2PW) * C::NLIST + lrow(i)) * TPA + sub];
 #pragma unroll
                         for (int e0 = 0; e0 < PW; e0 += W) {
-                            if (k0 + e0 == NM_PRIO_SW) prio_swap();
+                            if (k0 + e0 == PRIO_SW) prio_swap();
                             if (k0 + e0 < mine) {
                                 int jj[W];
                                 bool ok[W];
@@ -2067,7 +2080,7 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
                 wn = nb64[((size_t)(min(k0 + 8, MAXNB / TPA - 8) >> 3) * C::NLIST + lrow(i)) * TPA + sub];
 #pragma unroll
                 for (int e0 = 0; e0 < 8; e0 += W) {
-                    if (k0 + e0 == NM_PRIO_SW) prio_swap();
+                    if (k0 + e0 == PRIO_SW) prio_swap();
                     if (k0 + e0 < mine) {
                         double dx[W], dy[W], dz[W], r2[W], y[W], t[W];
                         bool in[W]; // (switched off by zeroing 1 / r^2 after the reciprocal, as in pair_pre)
@@ -2153,7 +2166,7 @@ __device__ __forceinline__ void Replica<C>::pair_loop_sc(double invL, double &ea
                 wn = nb64[((size_t)(min(k0 + 8, MAXNB / TPA - 8) >> 3) * C::NLIST + lrow(i)) * TPA + sub];
 #pragma unroll
                 for (int e0 = 0; e0 < 8; e0 += W) {
-                    if (k0 + e0 == NM_PRIO_SW) prio_swap();
+                    if (k0 + e0 == PRIO_SW) prio_swap();
                     if (k0 + e0 < mine) {
                         double dx[W], dy[W], dz[W], r2[W], y[W], t[W], hh[W], rj[W], q2[W], rm[W], rn[W], fp[W];
                         bool in[W];
