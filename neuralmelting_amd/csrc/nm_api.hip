@@ -655,6 +655,14 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
         }
         if (pick_q(c, want, note) != NM_OK) { g_create_error = c->err; free_ctx(c); return NM_ERR_HIP; } // (workgroups per replica: see pick_q)
         if (!note.empty()) note = "nm_create: " + note;
+        if (testing())
+            if (const char *e = std::getenv("NM_TEST_CENSUS_BASE")) { // tests: start the monotonic census counters just below the value at
+                // which issue_block zeroes them (a wrap is otherwise 16 million launches away)
+                const unsigned int b = (unsigned int)std::strtoul(e, nullptr, 0);
+                std::vector<unsigned int> w(census_words(c->nslots), b);
+                CHK(hipMemcpy(c->d_census, w.data(), sizeof(unsigned int) * w.size(), hipMemcpyHostToDevice));
+                c->census_base = c->census_cbase = b;
+            }
         {
             hipDeviceProp_t prop;
             CHK(hipGetDeviceProperties(&prop, cfg->device));

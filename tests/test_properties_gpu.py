@@ -353,6 +353,39 @@ def test_every_getter_and_setter_looks_at_a_halted_queue_first(monkeypatch, firs
     a.close()
 
 
+def test_census_counters_are_zeroed_before_they_could_wrap(monkeypatch):
+    """The residency census counts on counters that only grow (no memset in front of a launch, round 4); the host zeroes them, and the
+    bases the kernels compare with, once a base passes 0x3F000000 — 16 million launches into a run.  Here the counters start 300 below
+    that value (NM_TEST_CENSUS_BASE, honoured under NM_TESTING only), so the second launch crosses it: every launch must still gather
+    (no status, no heal) and the chains must be bit for bit those of a context that started from zero."""
+    import neuralmelting_amd as nm
+    from neuralmelting_amd import lattice
+    P, T = grids(8, 8)
+    x, v, box, d = lattice.init_states(4, P, T, 0.03125, 0.03125)
+
+    def run():
+        e = nm.Engine(256, P, T)
+        assert e.cus_per_replica == 4
+        e.set_state(x, v, box, d)
+        for step in range(4):
+            e.set_step(step)
+            e.run_block(6)
+            e.adapt()
+            e.exchange(count=False)
+        e.synchronize()
+        out = (e.thermo(), e.get_state()[0], e.perm(), e.heals, e.note(), e.status().copy())
+        e.close()
+        return out
+
+    ref = run()
+    monkeypatch.setenv('NM_TEST_CENSUS_BASE', str(0x3F000000 - 300))
+    got = run()
+    assert got[3] == 0 and got[4] == '' and (got[5] == 0).all()
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1], ref[1])
+    np.testing.assert_array_equal(got[2], ref[2])
+
+
 def test_a_grid_of_twice_the_chip_heals_to_the_resident_one(monkeypatch):
     """NM_OVERSUBSCRIBE=1: 128 replicas of 2048 atoms at 4 workgroups each run as two rounds of clusters, every cluster with its own
     residency census.  A launch whose censuses fail (injected) leaves the replicas untouched; the library re-issues it on the resident
