@@ -1165,21 +1165,26 @@ struct Replica {
             [[maybe_unused]] double vpre = 0.0, ppre = 0.0;
             prio_begin();
             if (i < a1) {
-                const double xi = __builtin_fma(px[i], invL, 0.5), yi = __builtin_fma(py[i], invL, 0.5), zi = __builtin_fma(pz[i], invL, 0.5); // (pair_pre)
+                // (the row's first list word is asked for FIRST: the first gathers wait for it and for nothing else)
+                [[maybe_unused]] unsigned long long wn_first = 0ull;
+                if constexpr (C::LIST_LDS) wn_first = ((const unsigned long long *)nbr_cur())[(size_t)lrow(i) * TPA + sub];
                 const int c = cnt[i];
-                if constexpr (SPREAD) {
-                    // lanes 0, 1, 2 of the row will integrate the x, y, z component (the epilogue below): what they need of the atom is
-                    // asked for NOW and arrives under the neighbours' arithmetic — read in the epilogue, two dependent LDS round trips
-                    // stood behind every pair loop while the LDS pipe was busy with the other waves' gathers
-                    if (fuse && sub < 3) { vpre = vx.ptr()[sub * NMAX + i]; ppre = px.ptr()[sub * NMAX + i]; }
-                }
+                const double xi = __builtin_fma(px[i], invL, 0.5), yi = __builtin_fma(py[i], invL, 0.5), zi = __builtin_fma(pz[i], invL, 0.5); // (pair_pre)
+                if constexpr (SPREAD && !C::LIST_LDS) { if (fuse && sub < 3) { vpre = vx.ptr()[sub * NMAX + i]; ppre = px.ptr()[sub * NMAX + i]; } }
                 if constexpr (C::LIST_LDS) {
                     constexpr int W = NM_PAIR_W, PW = C::PW, BITS = 8 * (int)sizeof(IdxT);
                     static_assert(PW % W == 0, "");
                     const unsigned long long *nb64 = (const unsigned long long *)nbr_cur();
                     const int mine = (c - sub + TPA - 1) / TPA; // neighbours of atom i that this thread handles: slots sub, sub+TPA, ...
                     constexpr int KLAST = MAXNB / TPA - PW;     // first entry of a thread's last list word
-                    unsigned long long wn = nb64[(size_t)lrow(i) * TPA + sub];
+                    unsigned long long wn = wn_first;
+                    if constexpr (SPREAD) {
+                        // lanes 0, 1, 2 of the row will integrate the x, y, z component (the epilogue below): what they need of the atom is
+                        // asked for NOW — behind the first list word, which the first gathers wait for — and arrives under the neighbours'
+                        // arithmetic.  Read in the epilogue, two dependent LDS round trips stood behind every pair loop while the LDS pipe
+                        // was busy with the other waves' gathers.
+                        if (fuse && sub < 3) { vpre = vx.ptr()[sub * NMAX + i]; ppre = px.ptr()[sub * NMAX + i]; }
+                    }
                     TLINE(1); // (experiment build: the row's prologue is issued)
                     for (int k0 = 0; k0 < mine; k0 += PW) {     // one conflict-free 8-byte read = PW of them
                         const unsigned long long wd = wn;

@@ -10,10 +10,18 @@ from neuralmelting_amd import lattice, _lib
 ROWS = int(os.environ.get('NM_TL_ROWS', '8'))   # 8 rows x 8 = 64 replicas (Q = 4); 4 rows = 32 replicas (Q = 8)
 P = np.linspace(1, 8, 8, dtype=np.float32); T = np.linspace(.25, 2.5, 8, dtype=np.float32)
 x, v, box, d = lattice.init_states(4, P, T, 0.03125, 0.03125, row0=0, nrows=ROWS)
-e = nm.Engine(256, P, T, ppos=0.0, pvol=0.0, nstps=16, row0=0, nrows=ROWS)
-e.set_state(x, v, box, d)
-for s in range(3):
-    e.set_step(s); e.run_block(24); e.adapt()
+EQ = int(os.environ.get('NM_TL_EQUIL', '0'))   # > 0: the bench's moves (PMC / VMC 0.125 each, 8 steps), that many cycles of 128 moves first, with the
+# exchange — the timeline is then that of an equilibrated replica (slot 0 after the last sweep), list rebuilds included
+if EQ:
+    e = nm.Engine(256, P, T, row0=0, nrows=ROWS)
+    e.set_state(x, v, box, d)
+    for s in range(EQ):
+        e.set_step(s); e.run_block(128); e.adapt(); e.exchange(count=False)
+else:
+    e = nm.Engine(256, P, T, ppos=0.0, pvol=0.0, nstps=16, row0=0, nrows=ROWS)
+    e.set_state(x, v, box, d)
+    for s in range(3):
+        e.set_step(s); e.run_block(24); e.adapt()
 e.synchronize()
 L = _lib.load()
 L.nm_tline_get.argtypes = [C.c_void_p, C.c_void_p]
@@ -64,3 +72,8 @@ for q in range(Q):
         vals = [np.median((t[q, w, e_, k] - last3) * 10.0) for k in (3, 4, 6, 7)]
         nxt = np.median((t[q, w, [k + 1 for k in e_], 0] - last3) * 10.0)
         print('      %d   %7.0f %7.0f %7.0f %7.0f %7.0f' % (w, vals[0], vals[1], vals[2], vals[3], nxt))
+# evaluations that rebuilt their list: entry -> "after rebuild" stamp of the workgroup's slowest wave, sorted (the short ones are plain entries)
+ent = np.array([np.max(t[0, :, k, 2]) - np.min(t[0, :, k, 0]) for k in e_]) * 10.0
+srt = np.sort(ent)
+print('entry -> past the rebuild decision / rebuild, workgroup 0, ns: median %.0f; evaluations above 1 us: %d of %d, their median %.0f, min %.0f'
+      % (np.median(ent), int((ent > 1000).sum()), len(ent), np.median(ent[ent > 1000]) if (ent > 1000).any() else 0, ent[ent > 1000].min() if (ent > 1000).any() else 0))
