@@ -199,12 +199,14 @@ def run_leg(args, env, scaling, with_cpu):
         eng.set_step(step)
         eng.run_block(mod)
         if recorder is not None:
-            recorder.cycle(eng)          # the previous cycle's files are written while this block runs; this cycle's rows and frames go D2H
+            recorder.cycle(eng)          # this cycle's outputs are snapshotted behind the block (in front of gen_mc_params, which zeroes the counters)
         eng.adapt()
         if split:
             exchange_split(step)
         else:
             eng.exchange(count=False)
+        if recorder is not None:
+            recorder.drain(eng)          # the PREVIOUS cycle's snapshot is fetched and handed to the writer thread while this block runs
 
     def fence():
         eng.synchronize()
@@ -282,6 +284,12 @@ def run_leg(args, env, scaling, with_cpu):
         rdir = args.record_dir or tempfile.mkdtemp(prefix='nm_record_')
         os.makedirs(rdir, exist_ok=True)
         recorder = Recorder(rdir, k0, ns, natoms)
+        for _ in range(4):        # warm-up of the recording path, untimed like every other warm-up: the first snapshots allocate the side stream and the
+            cycle(step)           # device / pinned host buffers, and the block kernel itself runs 2-3 % slower for the first few cycles that touch them
+            step += 1             # (scripts/probe_record.py: 5.85 ms per block in the first ten recorded cycles of a context, 5.66-5.71 ms in every
+        recorder.flush()          # later region, recording or not)
+        recorder.d2h_s = recorder.write_s = 0.0
+        recorder.bytes = 0
         step, dt_r, _, launches_r, kms_r, st_r, _ = timed(args.steps, step)
         rec = recorder.summary(args.steps)
         recorder = None
@@ -337,7 +345,7 @@ def run_leg(args, env, scaling, with_cpu):
             'metric': metric, 'value': sus['value'], 'unit': 'sweeps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': sus['ms_per_step'], 'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'equilibration_cycles': equil, 'timed_from_cycle': step - args.steps * (2 if args.record else 1) if args.equil > 0 else args.warmup,
+            'equilibration_cycles': equil, 'timed_from_cycle': step - args.steps * (2 if args.record else 1) - (4 if args.record else 0) if args.equil > 0 else args.warmup,
             'window': {k: win[k] for k in keys},
             'sustained': {k: sus[k] for k in keys},
             'config': {'workload': '%s; %s %d^3 cells (%d atoms), %d replicas on rank 0 (%d in all), MOD=%d, %s PMC 0.125 / VMC '
@@ -370,9 +378,13 @@ def run_leg(args, env, scaling, with_cpu):
         if rec is not None:
             on = ns_total * mod * args.steps / dt_r
             out['record'] = dict(rec, outputs_off=sus['value'], outputs_on=on, io_share=1.0 - on / sus['value'],
-                                 ms_per_step_on=dt_r / args.steps * 1e3, kernel_avg_ms_on=kms_r / max(launches_r, 1),
-                                 note='rank 0; every cycle: thermo rows + positions D2H, 17-column .thrm row and N+1-line .traj frame per replica '
-                                      'appended by nm_append_outputs (remcmc:235-256) on a helper thread while the next block runs')
+                                 ms_per_step_on=dt_r / args.steps * 1e3, kernel_avg_ms_on=kms_r / max(launches_r, 1), launches_on=launches_r,
+                                 slot_block_ms_mean_on=float((st_r[:, 4] / np.maximum(st_r[:, 6], 1.0) * 1e-5).mean()),
+                                 slot_block_ms_max_on=float((st_r[:, 4] / np.maximum(st_r[:, 6], 1.0) * 1e-5).max()),
+                                 list_rebuilds_per_sweep_on=float(st_r[:, 1].sum() / (ns * mod * args.steps)),
+                                 note='rank 0; every cycle: thermo rows + positions snapshotted behind the block (nm_snapshot: device copy, D2H on a side stream), '
+                                      'fetched one cycle later; 17-column .thrm row and N+1-line .traj frame per replica appended by nm_append_outputs '
+                                      '(remcmc:235-256) on a helper thread while the next block runs')
             out['value'], out['ms_per_step'] = on, dt_r / args.steps * 1e3
             out['metric'] = metric + ' (outputs on)'
             out['config']['workload'] = out['config']['workload'].replace('outputs off', 'outputs ON every cycle (-sc 0)')
@@ -401,15 +413,17 @@ class Recorder:
         self.B, self.C, self.ns, self.natoms = B, C, ns, natoms
         self.thrm = (C.c_char_p * ns)(*[os.path.join(rdir, 'bench.%04d.thrm' % (k0 + k)).encode() for k in range(ns)])
         self.traj = (C.c_char_p * ns)(*[os.path.join(rdir, 'bench.%04d.traj' % (k0 + k)).encode() for k in range(ns)])
-        self.pending, self.thread, self.err = None, None, None
+        self.snaps, self.eng, self.thread, self.err = 0, None, None, None
         self.d2h_s = self.write_s = 0.0
         self.bytes = 0
 
     def _write(self, rows, x, box):
         t0 = time.perf_counter()
+        if os.environ.get('NM_BENCH_NO_WRITE'):   # dev: isolate the cost of the copies from that of formatting and files
+            return
         B = self.B
         rc = B.load().nm_append_outputs(self.ns, self.natoms, self.thrm, self.traj, rows.ctypes.data_as(B.c_double_p),
-                                        x.ctypes.data_as(B.c_double_p), box.ctypes.data_as(B.c_double_p), 0)
+                                        x.ctypes.data_as(B.c_double_p), box.ctypes.data_as(B.c_double_p), 8)
         if rc != 0:
             self.err = IOError('nm_append_outputs failed (%d)' % rc)
         self.write_s += time.perf_counter() - t0
@@ -422,28 +436,36 @@ class Recorder:
                 raise self.err
 
     def cycle(self, eng):
-        """called right after run_block was enqueued: start writing the PREVIOUS cycle, then fetch this one (waits for the block)"""
-        import threading
-        if self.pending is not None:
-            self._join()
-            self.thread = threading.Thread(target=self._write, args=self.pending)
-            self.thread.start()
-            self.pending = None
-        t0 = time.perf_counter()
-        xs, _, boxs, _ = eng.get_state(velocities=False)
-        rows = eng.thermo()
-        self.d2h_s += time.perf_counter() - t0     # (includes waiting for the block itself)
-        self.pending = (np.ascontiguousarray(rows), np.ascontiguousarray(xs), np.ascontiguousarray(boxs))
+        """called right after run_block was enqueued: this cycle's outputs are snapshotted behind the block (Engine.snapshot: the copy to the
+        host runs beside the stream)"""
+        eng.snapshot()
+        self.snaps += 1
+        self.eng = eng
         self.bytes += self.ns * (17 * 11 + 1 + (self.natoms + 1) * 34)   # ' %.4E' = 11 bytes per number
+
+    def drain(self, eng):
+        """called once the cycle is queued: the previous cycle's snapshot is fetched (it waits for that copy only) and handed to the writer thread"""
+        import threading
+        if self.snaps > 1:
+            t0 = time.perf_counter()
+            rows, xs, boxs = eng.snapshot_fetch()
+            self.snaps -= 1
+            self.d2h_s += time.perf_counter() - t0
+            self._join()
+            self.thread = threading.Thread(target=self._write, args=(np.ascontiguousarray(rows), np.ascontiguousarray(xs), np.ascontiguousarray(boxs)))
+            self.thread.start()
 
     def flush(self):
         self._join()
-        if self.pending is not None:
-            self._write(*self.pending)
-            self.pending = None
+        while self.snaps:
+            t0 = time.perf_counter()
+            rows, xs, boxs = self.eng.snapshot_fetch()
+            self.snaps -= 1
+            self.d2h_s += time.perf_counter() - t0
+            self._write(np.ascontiguousarray(rows), np.ascontiguousarray(xs), np.ascontiguousarray(boxs))
 
     def summary(self, steps):
-        return {'write_ms_per_step': self.write_s / steps * 1e3, 'fetch_ms_per_step_incl_block_wait': self.d2h_s / steps * 1e3,
+        return {'write_ms_per_step': self.write_s / steps * 1e3, 'fetch_ms_per_step': self.d2h_s / steps * 1e3,
                 'text_bytes_per_step': self.bytes // max(steps, 1)}
 
 

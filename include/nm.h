@@ -118,6 +118,13 @@ int nm_run_md(nm_ctx *ctx, int nsteps);
 int nm_run_block(nm_ctx *ctx, int mod);
 /* rows[nslots][17] in the column order of remcmc:208 (values of the last nm_run_block; call before nm_adapt) */
 int nm_get_thermo(nm_ctx *ctx, double *rows);
+/* write_outputs (remcmc:259-286) without stopping the stream.  nm_snapshot, queued right behind nm_run_block and in front of nm_adapt, keeps what a
+   recorded cycle writes (the 17 thermo columns, positions, box) as of that point; a side stream brings it to the host while the context's stream goes on with
+   nm_adapt, nm_exchange and the next block.  nm_snapshot_fetch hands the OLDEST pending snapshot out — rows[nslots][17], x[nslots][3N], box[nslots], any
+   of them NULL — and waits for that copy only.  At most two may be pending (a driver fetches cycle s - 1 after queueing cycle s); NM_ERR_STATE otherwise.
+   Neither call looks at the queue's outcome: an error is reported by the next synchronising call as always. */
+int nm_snapshot(nm_ctx *ctx);
+int nm_snapshot_fetch(nm_ctx *ctx, double *rows, double *x, double *box);
 /* gen_mc_params: adapt dx, dv, dt, zero counters and ratios */
 int nm_adapt(nm_ctx *ctx);
 /* replica_exchange over the local pressure rows.  nswaps may be NULL (stays asynchronous). */

@@ -10,6 +10,7 @@
 #include "../../include/nm_distr.h"
 #include "../../include/nm_parse.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -96,6 +97,12 @@ struct nm_ctx {
     void *d_nbr;
     unsigned long long *d_prof; // diagnostic build only (NM_PROF)
     unsigned long long *d_tline; // experiment build only
+    // output snapshots (nm_snapshot / nm_snapshot_fetch): two slots, each a device copy and a pinned host copy of everything a recorded
+    // cycle writes (x, box, therm, steps, count, ratio, slot2buf); the D2H runs on a side stream so that the main stream never waits
+    hipStream_t side = nullptr;
+    struct Snap { double *d = nullptr, *h = nullptr; hipEvent_t taken = nullptr, landed = nullptr; bool pending = false; } snap[2];
+    size_t snap_doubles = 0;
+    int snap_head = 0, snap_count = 0; // oldest pending slot, number pending
     double *h_stage = nullptr;   // pinned host staging area (nm_set_state / nm_get_state)
     size_t stage_cap = 0;
     size_t trace_cap;
@@ -529,6 +536,14 @@ void free_ctx(nm_ctx *c)
                      c->d_status_acc, c->d_halt, c->d_rerun, c->d_order, c->d_last_ticks };
     for (void *q : ptrs) if (q) hipFree(q);
     if (c->h_stage) hipHostFree(c->h_stage);
+    if (c->side) hipStreamSynchronize(c->side);
+    for (auto &sn : c->snap) {
+        if (sn.d) hipFree(sn.d);
+        if (sn.h) hipHostFree(sn.h);
+        if (sn.taken) hipEventDestroy(sn.taken);
+        if (sn.landed) hipEventDestroy(sn.landed);
+    }
+    if (c->side) hipStreamDestroy(c->side);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -957,6 +972,94 @@ int nm_set_slots(nm_ctx *c, int nk, const int *slots, const double *x, const dou
         if (th) HIPCHK(c, hipMemcpyAsync(c->d_therm + 5 * bq, th + 5 * q, 5 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream)); // the caller's arrays (pageable: staged by the runtime) and the staging area are free again
+    return NM_OK;
+}
+
+// ---- output snapshots: write_outputs (remcmc:259-286) without stopping the stream.  nm_snapshot, queued right behind nm_run_block, copies what
+// a recorded cycle writes — positions, box, the 17 thermo columns' sources — device to device on the context's stream (behind the block, in front of
+// nm_adapt), and a side stream brings the copy to pinned host memory while the main stream goes on with nm_adapt, nm_exchange and the next block.
+// nm_snapshot_fetch hands the OLDEST pending snapshot out; it waits for that snapshot's copy only, never for the main stream.  Two slots: a driver
+// fetches cycle s - 1 after it has queued cycle s.  (nm_get_thermo + nm_get_state, the synchronous way, stop the GPU between two blocks for the
+// copies and the host's turn-around: 7 % of a recorded C2 run.)  Neither call looks at the queue's outcome: a block that stopped on an error is
+// reported by the next synchronising call as always, and its snapshot holds the state the block started from.
+static size_t snap_layout(const nm_ctx *c, size_t off[8])
+{
+    const size_t ns = c->nslots, n3 = (size_t)3 * c->N;
+    size_t o = 0;
+    off[0] = o; o += ns * n3;        // x
+    off[1] = o; o += ns;             // box
+    off[2] = o; o += 5 * ns;         // therm
+    off[3] = o; o += 3 * ns;         // steps
+    off[4] = o; o += 6 * ns;         // count
+    off[5] = o; o += (3 * ns + 1) / 2; // ratio (float)
+    off[6] = o; o += (ns + 1) / 2;   // slot2buf (int)
+    return o;
+}
+
+int nm_snapshot(nm_ctx *c)
+{
+    if (!c) return NM_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->snap_count == 2) return fail(c, NM_ERR_STATE, "nm_snapshot: two snapshots are pending; fetch one first (nm_snapshot_fetch)");
+    size_t off[8];
+    const size_t nd = snap_layout(c, off);
+    if (!c->side) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        c->snap_doubles = nd;
+        for (auto &sn : c->snap) {
+            HIPCHK(c, dalloc(&sn.d, nd));
+            HIPCHK(c, hipHostMalloc((void **)&sn.h, nd * sizeof(double), hipHostMallocDefault));
+            HIPCHK(c, hipEventCreateWithFlags(&sn.taken, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&sn.landed, hipEventDisableTiming));
+        }
+    }
+    nm_ctx::Snap &sn = c->snap[(c->snap_head + c->snap_count) & 1];
+    const size_t ns = c->nslots, n3 = (size_t)3 * c->N;
+    SnapArgs a;
+    a.x = c->d_x; a.box = c->d_box; a.therm = c->d_therm; a.steps = c->d_steps; a.count = c->d_count; a.ratio = c->d_ratio; a.slot2buf = c->d_slot2buf;
+    a.dst = sn.d;
+    const size_t cnt[7] = { ns * n3, ns, 5 * ns, 3 * ns, 6 * ns, 3 * ns, ns };
+    for (int q = 0; q < 7; ++q) { a.off[q] = off[q]; a.n[q] = cnt[q]; }
+    const unsigned int blocks = (unsigned int)std::min<size_t>((ns * n3 + 1023) / 1024, 64); // (a handful of CUs for a few microseconds, between two blocks)
+    hipLaunchKernelGGL(nm_snapshot_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(sn.taken, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->side, sn.taken, 0));
+    HIPCHK(c, hipMemcpyAsync(sn.h, sn.d, nd * sizeof(double), hipMemcpyDeviceToHost, c->side));
+    HIPCHK(c, hipEventRecord(sn.landed, c->side));
+    sn.pending = true;
+    ++c->snap_count;
+    return NM_OK;
+}
+
+int nm_snapshot_fetch(nm_ctx *c, double *rows, double *x, double *box)
+{
+    if (!c) return NM_ERR_ARG;
+    if (c->snap_count == 0) return fail(c, NM_ERR_STATE, "nm_snapshot_fetch: no snapshot is pending");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    nm_ctx::Snap &sn = c->snap[c->snap_head];
+    HIPCHK(c, hipEventSynchronize(sn.landed));
+    size_t off[8];
+    snap_layout(c, off);
+    const size_t ns = c->nslots, n3 = (size_t)3 * c->N;
+    const double *hx = sn.h + off[0], *hb = sn.h + off[1], *th = sn.h + off[2], *st = sn.h + off[3], *cn = sn.h + off[4];
+    const float *ra = (const float *)(sn.h + off[5]);
+    const int *m = (const int *)(sn.h + off[6]);
+    for (size_t k = 0; k < ns; ++k) {
+        const size_t b = (size_t)m[k];
+        if (rows) {
+            double *r = rows + k * NM_THERMO_COLS;
+            for (int q = 0; q < 5; ++q) r[q] = th[5 * b + q];
+            for (int q = 0; q < 3; ++q) r[5 + q] = st[3 * b + q];
+            for (int q = 0; q < 6; ++q) r[8 + q] = cn[6 * k + q];
+            for (int q = 0; q < 3; ++q) r[14 + q] = (double)ra[3 * k + q];
+        }
+        if (x) std::memcpy(x + k * n3, hx + b * n3, n3 * sizeof(double));
+        if (box) box[k] = hb[b];
+    }
+    sn.pending = false;
+    c->snap_head ^= 1;
+    --c->snap_count;
     return NM_OK;
 }
 

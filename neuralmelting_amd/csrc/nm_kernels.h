@@ -2677,6 +2677,21 @@ __global__ void nm_order_kernel(int nslots, const unsigned long long *ticks, int
     }
 }
 
+// nm_snapshot: everything a recorded cycle writes, copied in ONE launch (seven stream-ordered memcpys cost seven dispatch gaps per cycle)
+struct SnapArgs { const double *x, *box, *therm, *steps, *count; const float *ratio; const int *slot2buf; double *dst; size_t off[7], n[7]; };
+__global__ void nm_snapshot_kernel(const SnapArgs a)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+    const double *src[5] = { a.x, a.box, a.therm, a.steps, a.count };
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+        for (size_t i = t; i < a.n[q]; i += nt) a.dst[a.off[q] + i] = src[q][i];
+    float *rf = (float *)(a.dst + a.off[5]);
+    for (size_t i = t; i < a.n[5]; i += nt) rf[i] = a.ratio[i];
+    int *mi = (int *)(a.dst + a.off[6]);
+    for (size_t i = t; i < a.n[6]; i += nt) mi[i] = a.slot2buf[i];
+}
+
 // gen_mc_param (remcmc:726-745): one thread per slot
 __global__ void nm_adapt_kernel(int nslots, const int *slot2buf, double *steps, double *count, float *ratio, const int *halt)
 {

@@ -171,6 +171,19 @@ class Engine:
         self._settled(self.lib.nm_get_thermo(self.h, _dp(rows)))
         return rows
 
+    def snapshot(self):
+        """keep what a recorded cycle writes as of this point of the queue (call right behind run_block, in front of adapt); the copy to the host
+        runs beside the stream (nm_snapshot)"""
+        self._chk(self.lib.nm_snapshot(self.h))
+
+    def snapshot_fetch(self, positions=True):
+        """(rows[nslots][17], x[nslots][3N] or None, box[nslots]) of the oldest pending snapshot; waits for its copy only (nm_snapshot_fetch)"""
+        rows = np.empty((self.nslots, B.NM_THERMO_COLS))
+        x = np.empty((self.nslots, 3 * self.natoms)) if positions else None
+        box = np.empty(self.nslots)
+        self._chk(self.lib.nm_snapshot_fetch(self.h, _dp(rows), _dp(x) if positions else None, _dp(box)))
+        return rows, x, box
+
     def adapt(self):
         """gen_mc_params (remcmc:748-770)"""
         self._chk(self.lib.nm_adapt(self.h))

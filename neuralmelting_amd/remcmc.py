@@ -386,18 +386,17 @@ class Run:
                 eng.run_block(0)  # "run 0" of init_sample: thermo scalars of the initial states (remcmc:427)
         self.STEP = -1
         self.dump_samples_restart()
-        pending = None  # a recorded cycle waiting to be written: done while the next block runs on the GPU
+        snaps = 0  # recorded cycles whose outputs are on their way to the host (Engine.snapshot): fetched and written one cycle later, while the next
+        # block runs on the GPU — the stream never waits for the copies, the formatting or the files
         eng.synchronize()
         t_loop = time.perf_counter()
         for self.STEP in range(self.NSMPL):
             eng.set_step(self.STEP)
             eng.run_block(self.MOD)                       # gen_samples (asynchronous)
-            if pending is not None:
-                self._write_async(*pending)
-                pending = None
-            if (self.STEP + 1) > self.CUTOFF:             # remcmc:983-985
-                xs, _, boxs, _ = eng.get_state(velocities=False)
-                pending = (eng.thermo(), xs, boxs)
+            record = (self.STEP + 1) > self.CUTOFF        # remcmc:983-985
+            if record:
+                eng.snapshot()                            # the 17 thermo columns, positions and box as of here: before gen_mc_params zeroes the counters
+                snaps += 1
             eng.adapt()                                   # gen_mc_params
             if (self.STEP + 1) % self.REFREQ == 0:
                 self.dump_samples_restart()               # remcmc:990-992
@@ -405,8 +404,12 @@ class Run:
                 n = self.replica_exchange(self.STEP)
                 if self.VERBOSE:
                     self.log('%d replica exchanges performed' % n)
-        if pending is not None:
-            self._write_async(*pending)
+            while snaps > (1 if record else 0):           # the cycle before this one: write_outputs (remcmc:259-286), in cycle order
+                self._write_async(*eng.snapshot_fetch())
+                snaps -= 1
+        while snaps:
+            self._write_async(*eng.snapshot_fetch())
+            snaps -= 1
         self._write_join()
         eng.synchronize()
         self.loop_seconds = time.perf_counter() - t_loop   # the metric's clock: main loop, remcmc:977-995

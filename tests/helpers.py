@@ -144,6 +144,17 @@ class OracleEngine:
         if dxdvdt is not None: lp.d[sl] = np.array(dxdvdt, dtype=np.float64).reshape(nk, 3)
         if th is not None: lp.thermo[sl] = np.array(th, dtype=np.float64).reshape(nk, 5)
 
+    def snapshot(self):
+        if not hasattr(self, '_snaps'):
+            self._snaps = []
+        assert len(self._snaps) < 2, 'two snapshots are pending'
+        lp = self.loop
+        self._snaps.append((lp.rows().copy(), lp.x.copy(), lp.box.copy()))
+
+    def snapshot_fetch(self, positions=True):
+        rows, x, box = self._snaps.pop(0)
+        return rows, (x if positions else None), box
+
     def set_step(self, step): self.step = int(step)
     def run_block(self, mod): self.loop.run_block(mod, self.step)
     def thermo(self): return self.loop.rows()

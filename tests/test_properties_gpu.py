@@ -353,6 +353,56 @@ def test_every_getter_and_setter_looks_at_a_halted_queue_first(monkeypatch, firs
     a.close()
 
 
+def test_output_snapshots_equal_the_synchronous_reads_and_do_not_stop_the_stream():
+    """nm_snapshot / nm_snapshot_fetch (write_outputs without stopping the stream): a snapshot queued right behind a block, fetched a whole cycle
+    later — after nm_adapt has zeroed the counters, the exchange has re-labelled the slots and the next block has moved every atom — must hold
+    exactly what nm_get_thermo / nm_get_state returned at that point of an identical run; at most two may be pending, and fetching without one is
+    an error."""
+    import neuralmelting_amd as nm
+    from neuralmelting_amd import lattice
+    P, T = grids(2, 4)
+    x, v, box, d = lattice.init_states(4, P, T, 0.03125, 0.03125)
+
+    def engine():
+        e = nm.Engine(256, P, T)
+        e.set_state(x, v, box, d)
+        return e
+
+    ref = engine()
+    want = []
+    for step in range(3):
+        ref.set_step(step)
+        ref.run_block(12)
+        xs, _, bs, _ = ref.get_state(velocities=False)
+        want.append((ref.thermo(), xs, bs))
+        ref.adapt()
+        ref.exchange(count=False)
+    ref.close()
+
+    e = engine()
+    with pytest.raises(nm.NMError):
+        e.snapshot_fetch()                                   # nothing pending
+    got = []
+    for step in range(3):
+        e.set_step(step)
+        e.run_block(12)
+        e.snapshot()
+        e.adapt()
+        e.exchange(count=False)
+        if step == 1:
+            with pytest.raises(nm.NMError):
+                e.snapshot()                                 # a third one while two are pending
+            e.lib.nm_synchronize(e.h)                        # (clears the error text; the queue itself is fine)
+        if step >= 1:
+            got.append(e.snapshot_fetch())                   # the cycle before this one
+    got.append(e.snapshot_fetch())
+    e.close()
+    for (r, xs, bs), (r0, x0, b0) in zip(got, want):
+        np.testing.assert_array_equal(r, r0)
+        np.testing.assert_array_equal(xs, x0)
+        np.testing.assert_array_equal(bs, b0)
+
+
 def test_census_counters_are_zeroed_before_they_could_wrap(monkeypatch):
     """The residency census counts on counters that only grow (no memset in front of a launch, round 4); the host zeroes them, and the
     bases the kernels compare with, once a base passes 0x3F000000 — 16 million launches into a run.  Here the counters start 300 below
