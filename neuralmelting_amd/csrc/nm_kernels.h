@@ -66,9 +66,19 @@ constexpr int NVMAX = 16; // widest block reduction (the 16 raw moments of hmc_v
 #define TLINE(k) do { if (tl && tl_n < TL_EVALS && (tid & 63) == 0) tl[((size_t)(q * NW + (tid >> 6)) * TL_EVALS + tl_n) * 8 + (k)] = wall_clock64(); } while (0)
 // the same for the hand-over that follows evaluation tl_n - 1
 #define TLINE_PREV(k) do { if (tl && tl_n > 0 && tl_n <= TL_EVALS && (tid & 63) == 0) tl[((size_t)(q * NW + (tid >> 6)) * TL_EVALS + tl_n - 1) * 8 + (k)] = wall_clock64(); } while (0)
+#ifdef NM_TL_REBUILD // a second experiment build: slots 3 .. 7 of an evaluation hold stamps from INSIDE Replica::rebuild instead (scripts/probe_rebuild.py)
+#define RTL(k) do { if (tl && tl_n < TL_EVALS && (tid & 63) == 0) tl[((size_t)(q * NW + (tid >> 6)) * TL_EVALS + tl_n) * 8 + (k)] = wall_clock64(); } while (0)
+#undef TLINE
+#undef TLINE_PREV
+#define TLINE(k) do { if ((k) < 3 && tl && tl_n < TL_EVALS && (tid & 63) == 0) tl[((size_t)(q * NW + (tid >> 6)) * TL_EVALS + tl_n) * 8 + (k)] = wall_clock64(); } while (0)
+#define TLINE_PREV(k) do { } while (0)
+#else
+#define RTL(k) do { } while (0)
+#endif
 #else
 #define TLINE(k) do { } while (0)
 #define TLINE_PREV(k) do { } while (0)
+#define RTL(k) do { } while (0)
 #endif
 #ifdef NM_PROF
 #define NM_PROF_SLOTS 16
@@ -786,7 +796,9 @@ struct Replica {
         const double rt = (p.rc + p.skin) * sc16 + 1.8;                      // test radius in units of L / 65536 (< 2^15: L >= 2 rc)
         const unsigned int t2 = (unsigned int)__double2uint_rd(rt * rt) + 1u; // accepted: squared separation < t2
         int ovf = 0;
+        RTL(3); // conversion and the copy of the saved list's reference issued
         __syncthreads(); // the fixed-point copy is complete
+        RTL(4);
         if constexpr (C::LIST_LDS) {
             // TPA threads per row (the pair loop's grouping): thread (row, sub) tests the contiguous block of candidates
             // j = sub * CH + k, k < CH = ceil(N / TPA) — 32 per round, branch-free, one bit each.  An exclusive scan of the hit
@@ -826,6 +838,7 @@ struct Replica {
 #pragma unroll
                         for (int u = 0; u < 8; ++u) m = test16(m, xyi, zi, (unsigned int)cj[u], (unsigned int)(cj[u] >> 32), t2);
                     }
+                    RTL(5); // (last round of tests done)
                     m = __brev(m) >> (32 - ntest); // test b sat in bit ntest - 1 - b
                     const int valid = min(32, min(CH - k0, N - jb)); // candidates of this round that exist
                     m &= valid >= 32 ? 0xFFFFFFFFu : valid > 0 ? (1u << valid) - 1u : 0u;
@@ -856,6 +869,7 @@ struct Replica {
                 st_maxc = max(st_maxc, base);
                 if (base > MAXNB) { ovf = 1; base = MAXNB; }
                 if (active && sub == 0) cnt[i] = (unsigned short)base;
+                RTL(6); // (scan and appends done)
             }
         } else {
             static_assert(C::CH == 4 && sizeof(IdxT) == 2 && MAXNB % 4 == 0, "four 16-bit indices per 8-byte chunk");
@@ -928,6 +942,7 @@ struct Replica {
         if (p.inj_rebuild >= 0 && (int)st_rebuilds == p.inj_rebuild && q == p.inj_q % Q) ovf = 1; // fault injection (tests)
         st_rebuilds += 1.0;
         if (block_any<NW, NVMAX>(ovf != 0, red, parity)) status |= ST_LIST_OVERFLOW;
+        RTL(7);
     }
 
     // sum over the TPA consecutive lanes of an atom, total in the lane with sub == 0 (the other lanes hold partial garbage).

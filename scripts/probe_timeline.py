@@ -9,6 +9,8 @@ from neuralmelting_amd import lattice, _lib
 
 ROWS = int(os.environ.get('NM_TL_ROWS', '8'))   # 8 rows x 8 = 64 replicas (Q = 4); 4 rows = 32 replicas (Q = 8)
 P = np.linspace(1, 8, 8, dtype=np.float32); T = np.linspace(.25, 2.5, 8, dtype=np.float32)
+if os.environ.get('NM_TL_TREV'):   # the temperature grid upside down: the timeline's slot 0 is then the HOTTEST replica of the first pressure row
+    T = T[::-1].copy()
 x, v, box, d = lattice.init_states(4, P, T, 0.03125, 0.03125, row0=0, nrows=ROWS)
 EQ = int(os.environ.get('NM_TL_EQUIL', '0'))   # > 0: the bench's moves (PMC / VMC 0.125 each, 8 steps), that many cycles of 128 moves first, with the
 # exchange — the timeline is then that of an equilibrated replica (slot 0 after the last sweep), list rebuilds included
