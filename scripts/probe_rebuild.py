@@ -1,4 +1,4 @@
-"""dev probe (experiment build with -DNM_TL_REBUILD): where does a list rebuild of the 4^3 cluster kernel spend its time?  Stamps of slot 0's
+"""dev probe (experiment build with -DNM_TL_REBUILD: `make -C neuralmelting_amd/csrc exprb`): where does a list rebuild of the 4^3 cluster kernel spend its time?  Stamps of slot 0's
 evaluations: 0 entry, 3 conversion issued, 4 past the barrier, 5 tests done, 6 scan + appends done, 7 past the closing reduction.
     NM_TL_TREV=1 python scripts/probe_rebuild.py      (slot 0 = the hottest replica of the first pressure row)"""
 import ctypes as C, os, sys
