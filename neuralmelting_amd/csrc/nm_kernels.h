@@ -161,8 +161,8 @@ struct Cfg {
     // +8.6 %; 864 atoms at two per replica -4 %; 2048 atoms at two per replica -9 %.  Where it loses: the pair loop of the larger cells is
     // bound by the LDS pipe already (64 unrelated atoms per gather instruction), three atomics per entry make 2.4 times the LDS work of an
     // entry, only the own range's pairs go away (75 % of the entries at two workgroups per replica), and a cluster loses the epilogue that
-    // integrates and publishes a row's atom as soon as its force is known.  So HALF_ is set for the one-workgroup configuration of the
-    // lists in HBM only (CfgMidH, nm_api.hip); -DNM_HALF_LIST=2 builds every one-thread-per-row configuration with half lists for the A/B.
+    // integrates and publishes a row's atom as soon as its force is known.  At ONE workgroup per replica it pays at 2048 atoms too (256 replicas:
+    // +10 %).  So HALF_ is set for the one-workgroup configurations of the lists in HBM only (CfgMidH, CfgLargeH, nm_api.hip); -DNM_HALF_LIST=2 builds every one-thread-per-row configuration with half lists for the A/B.
     static constexpr bool HALF = !LIST_LDS_ && TPA_ == 1 && POT_ == 0 && (NM_HALF_LIST == 2 || (NM_HALF_LIST == 1 && HALF_));
     static constexpr int BLOCK = BLOCK_, TPA = TPA_, NW = BLOCK_ / 64, G = BLOCK_ / TPA_, NMAX = NMAX_, MAXNB = MAXNB_;
     static constexpr bool LIST_LDS = LIST_LDS_, SAVE_LDS = SAVE_LDS_;

@@ -226,7 +226,7 @@ def test_tape_replay_parity(oracle):
     e.close()
 
 
-# every instantiation nm_api.hip's launch_kind can pick: 5^3 / 6^3 -> CfgMidH (Q = 1: half lists), CfgMid (Q = 2), CfgMidQ4, CfgMidQ8; 8^3 -> CfgLarge (Q = 1, 2, 4)
+# every instantiation nm_api.hip's launch_kind can pick: 5^3 / 6^3 -> CfgMidH (Q = 1: half lists), CfgMid (Q = 2), CfgMidQ4, CfgMidQ8; 8^3 -> CfgLargeH (Q = 1: half lists), CfgLarge (Q = 2, 4)
 LARGE_CELL_CASES = [(sz, q) for sz in (5, 6) for q in (1, 2, 4, 8)] + [(8, 1), (8, 2), (8, 4)]
 
 
