@@ -828,7 +828,8 @@ struct Replica {
 #pragma unroll 1
                     for (int b0 = 0; b0 < ntest; b0 += 8) { // eight candidates in flight: all eight reads first, then the tests (written as
                         // one loop the compiler put `s_waitcnt lgkmcnt(0)` behind every single read: 32 LDS latencies in a row per thread,
-                        // half of a rebuild)
+                        // half of a rebuild.  Round 4 tried the NEXT group's reads ahead of the current group's tests (sixteen more
+                        // registers): -0.8 % on C2, dropped)
                         unsigned long long cj[8];
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
