@@ -45,14 +45,16 @@ typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 192, unsigned char, true, true, 0
 typedef Cfg<NM_SMALL_BLOCK, NM_SMALL_TPA, 256, 256, unsigned char, true, true, 1> CfgSmallSC;
 typedef Cfg<NM_SMALL_BLOCK, 2 * NM_SMALL_TPA, 256, 256, unsigned char, true, true, 1, 128, true, true> CfgSmallSCQ2; // (own rows, two lists)
 typedef Cfg<NM_SMALL_BLOCK, 4 * NM_SMALL_TPA, 256, 256, unsigned char, true, true, 1, 64, true, true> CfgSmallSCQ4;
-typedef Cfg<512, 1, 864, 160, unsigned short, false, true> CfgMid;     // N <= 864: list in HBM/L2, saved copies in LDS (here: at 2 workgroups per replica)
+typedef Cfg<512, 1, 864, 192, unsigned short, false, true> CfgMid;     // N <= 864: list in HBM/L2, saved copies in LDS (here: at 2 workgroups per replica)
 // the same at ONE workgroup per replica (more replicas than CUs: the reference's run.sh setting): every pair lies inside the workgroup and
 // is listed once (Cfg::HALF, nm_kernels.h)
-typedef Cfg<512, 1, 864, 160, unsigned short, false, true, 0, 864, true, false, true> CfgMidH;
+typedef Cfg<512, 1, 864, 192, unsigned short, false, true, 0, 864, true, false, true> CfgMidH;
 // cluster variants: own atoms 216 / 108
-typedef Cfg<512, 2, 864, 160, unsigned short, false, true> CfgMidQ4;
-// 8 workgroups per replica: 108 own atoms, whose list rows (16-bit, 35 KB) fit in LDS once the saved velocities moved to the spill
-typedef Cfg<512, 4, 864, 160, unsigned short, true, true, 0, 108, false> CfgMidQ8;
+typedef Cfg<512, 2, 864, 192, unsigned short, false, true> CfgMidQ4;
+// 8 workgroups per replica: 108 own atoms, whose list rows (16-bit, 41 KB at 192 slots) fit in LDS once the saved velocities moved to the spill.
+// 192 list slots per atom since round 4 (160 before): at the skin of 0.55 that these sizes now run with, the dense crystals of the P* = 7.5-8 rows
+// reach 147 entries (scripts/probe_maxrow6.py)
+typedef Cfg<512, 4, 864, 192, unsigned short, true, true, 0, 108, false> CfgMidQ8;
 // N <= 2048: saved copies spill to HBM as well.  224 list slots: the list lives in HBM, so slots are cheap, and at skin 0.6 the dense
 // crystals (P* = 8: 140 neighbours inside 3.1, the next shell of 36 just beyond) came within ~10 % of the 160 there were
 typedef Cfg<512, 1, 2048, 224, unsigned short, false, false> CfgLarge;
@@ -604,7 +606,10 @@ int nm_create(const nm_config *cfg, nm_ctx **out)
     // the O(N^2) rebuild of the larger cells favours fewer rebuilds (0.45: 6^3 -10 %, 8^3 -45 % per move)
     // (8^3, equilibrated chains, where a rebuild costs ~10 evaluations: 0.6 gives 107 ms per launch of C5's share against 121 at 0.45,
     // for +7 % while the chains still reject everything; 0.75 overflows the 160 list slots of the dense crystals)
-    c->skin = cfg->natoms <= 256 ? 0.4 : cfg->natoms <= 1024 ? 0.45 : 0.6; // (256 atoms, equilibrated: 7.1 / 6.8 / 6.8 ms per launch at 0.3 / 0.4 / 0.5)
+    c->skin = cfg->natoms <= 512 ? 0.4 : cfg->natoms <= 1024 ? 0.55 : 0.6; // (256 atoms, equilibrated: 7.1 / 6.8 / 6.8 ms per launch at 0.3 / 0.4 / 0.5)
+    // (round 4, sustained, same box each: 500 atoms at one workgroup per replica 1.385 / 1.411 / 1.392 / 1.390 M sweeps/s at 0.35 / 0.40 / 0.45 / 0.50;
+    //  864 atoms: C3 share (Q = 8) 352 / 359 / 368 / 372 / 370 k at 0.40 / 0.45 / 0.50 / 0.55 / 0.60, 256 replicas at Q = 1 615 / 617 / 632 / 642 k at
+    //  0.40 / 0.45 / 0.50 / 0.55: the O(N^2) rebuild of the larger cells wants fewer rebuilds; 0.45 for both until then)
     if (const char *e = std::getenv("NM_SKIN")) { const double v = std::atof(e); if (v > 0.0 && v < 1.0) c->skin = v; }
     c->lat = 1.122; c->mass = 1.0; c->kB = 1.0; c->mvv2e = 1.0; c->ftm2v = 1.0; c->nktv2p = 1.0;
     c->rc = 2.5; c->pot = 0;

@@ -117,3 +117,27 @@ def test_equilibrated_8cubed_lists_keep_clear_of_their_slots():
     assert slots == 224
     assert st[:, 1].sum() > 30 * 32                      # the lists were rebuilt many times
     assert 130 <= st[:, 8].max() <= 0.85 * slots, st[:, 8].max()
+
+
+def test_equilibrated_6cubed_lists_keep_clear_of_their_slots():
+    """The 864-atom kernels keep 192 list slots per atom since round 4 (160 before) and run with a skin of 0.55 (list radius 3.05).  The densest
+    states of BASELINE config 3 are those of its two highest pressure rows: their 2 x 16 replicas — C3's share of a GPU, 8 workgroups per replica,
+    the lists in LDS — run for 30 cycles (equilibrated chains), and the longest row any rebuild produced must stay well below the slots there are."""
+    import neuralmelting_amd as nm
+    P = np.linspace(1.0, 8.0, 16, dtype=np.float32)
+    T = np.linspace(0.25, 2.5, 16, dtype=np.float32)
+    x, v, box, d = lattice.init_states(6, P, T, 0.03125, 0.03125, row0=14, nrows=2)
+    e = nm.Engine(864, P, T, row0=14, nrows=2)
+    assert e.cus_per_replica == 8
+    e.set_state(x, v, box, d)
+    for step in range(30):
+        e.set_step(step)
+        e.run_block(64)
+        e.adapt()
+        e.exchange(count=False)
+    e.synchronize()
+    st = e.stats()
+    e.close()
+    assert st[0, 9] == 192
+    assert st[:, 1].sum() > 30 * 32
+    assert 120 <= st[:, 8].max() <= 0.85 * 192, st[:, 8].max()
