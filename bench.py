@@ -229,9 +229,16 @@ def run_leg(args, env, scaling, with_cpu):
         eng.stats(reset=True)
         heals0 = getattr(eng, 'heals', 0)
         t0 = time.perf_counter()
-        for _ in range(nsteps):
-            cycle(step)
-            step += 1
+        if recorder is None and not split and hasattr(eng, 'run_cycles') and not os.environ.get('NM_BENCH_SINGLE_CALLS'):
+            # outputs off: the K cycles as ONE call (nm_run_cycles: where the grid runs as clusters, one launch in which only the replicas of a
+            # pressure row wait for one another; the same chains, bit for bit, as the loop of single calls below)
+            eng.set_step(step)
+            eng.run_cycles(nsteps, mod)
+            step += nsteps
+        else:
+            for _ in range(nsteps):
+                cycle(step)
+                step += 1
         if recorder is not None:
             recorder.flush()
         fence()
@@ -316,10 +323,13 @@ def run_leg(args, env, scaling, with_cpu):
             k_avg_s = max((kms_ / max(launches_, 1)) * 1e-3, 1e-12)
             evals = st_[:, 0].sum()
             mean_pairs = st_[:, 3].sum() / max(st_[:, 2].sum(), 1.0)
+            cycles_per_launch = args.steps / max(launches_, 1)             # 1 with single calls, `steps` when nm_run_cycles made one launch of the region
+            sweeps_per_launch = ns * mod * cycles_per_launch
             flop_alg_launch = evals_alg * sweeps_per_launch * mean_pairs * FLOP_PER_PAIR
             blk_ms = st_[:, 4] / np.maximum(st_[:, 6], 1.0) * 1e-5          # per slot: mean time of its blocks (100 MHz ticks -> ms)
             return {'value': ns_total * mod * args.steps / dt_, 'ms_per_step': dt_ / args.steps * 1e3,
-                    'kernel_avg_ms': k_avg_s * 1e3, 'launches': launches_,
+                    'kernel_avg_ms': k_avg_s * 1e3, 'launches': launches_, 'cycles_per_launch': cycles_per_launch,
+                    'algorithmic_bytes_per_launch': bytes_per_sweep * sweeps_per_launch,
                     'achieved': flop_alg_launch / k_avg_s / 1e12, 'frac': flop_alg_launch / k_avg_s / 1e12 / FP64_VEC_PEAK_TF,
                     'algorithmic_flop_per_launch': flop_alg_launch,
                     'executed': evals * mean_pairs * FLOP_PER_PAIR / max(kms_ * 1e-3, 1e-12) / 1e12,
@@ -333,10 +343,10 @@ def run_leg(args, env, scaling, with_cpu):
 
         win = numbers(dt_w, launches_w, kms_w, st_w)
         sus = numbers(dt, launches, kms, st) if args.equil > 0 else win
-        prof = measured_profile((args.config + ('_iter' if args.iterative else '')) if not custom else None, ns, mod)
+        prof = measured_profile((args.config + ('_iter' if args.iterative else '')) if not custom else None, ns, mod, sus['cycles_per_launch'])
         grid = '%dx%d PxT grid%s' % (npn, tn, '' if world == 1 else ' over %d GPUs' % world)
         metric = 'MC sweeps/sec (whole node), %s %d^3 cells, %s' % (el, sz, grid)
-        keys = ('value', 'ms_per_step', 'kernel_avg_ms', 'frac', 'frac_executed', 'evals_per_sweep', 'list_rebuilds_per_sweep',
+        keys = ('value', 'ms_per_step', 'kernel_avg_ms', 'cycles_per_launch', 'frac', 'frac_executed', 'evals_per_sweep', 'list_rebuilds_per_sweep',
                 'slot_block_ms_mean', 'slot_block_ms_max')
         out = {
             # value = the SUSTAINED rate: `steps` timed cycles of equilibrated chains (HMC accepting about half its trajectories, step
@@ -361,7 +371,8 @@ def run_leg(args, env, scaling, with_cpu):
             # across moves: ~6.26 evaluations per sweep); traffic = HBM bytes per launch from the committed rocprofv3 PMC passes.
             'roofline': {'bound': 'fp64-valu', 'achieved': sus['achieved'], 'peak': FP64_VEC_PEAK_TF, 'unit': 'TFLOP/s',
                          'frac': sus['frac'], 'traffic': prof.get('traffic'), 'traffic_range': prof.get('traffic_range'),
-                         'kernel': 'nm_block_kernel', 'kernel_avg_ms': sus['kernel_avg_ms'], 'launches': sus['launches'],
+                         'kernel': 'nm_cycles_kernel' if sus['cycles_per_launch'] > 1 else 'nm_block_kernel', 'kernel_avg_ms': sus['kernel_avg_ms'],
+                         'launches': sus['launches'], 'cycles_per_launch': sus['cycles_per_launch'],
                          'launches_that_did_no_work': heals_s,   # blocks re-issued at fewer workgroups per replica inside the region (not in kernel_avg_ms)
                          'algorithmic_flop_per_launch': sus['algorithmic_flop_per_launch'], 'algorithmic_evals_per_sweep': evals_alg,
                          'executed': sus['executed'], 'frac_executed': sus['frac_executed'], 'evals_per_sweep': sus['evals_per_sweep'],
@@ -373,7 +384,7 @@ def run_leg(args, env, scaling, with_cpu):
             # the HBM line the contract asks for: algorithmic bytes (48 N + 24 N PHMC per sweep) / kernel time, << 1 % by design
             'roofline_hbm': {'bound': 'hbm', 'achieved': sus['hbm_gbs_algorithmic'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                              'frac': sus['hbm_gbs_algorithmic'] / HBM_PEAK_GBS, 'traffic': prof.get('traffic'),
-                             'algorithmic_bytes_per_launch': bytes_per_sweep * sweeps_per_launch},
+                             'algorithmic_bytes_per_launch': sus['algorithmic_bytes_per_launch']},
         }
         if rec is not None:
             on = ns_total * mod * args.steps / dt_r
@@ -469,11 +480,12 @@ class Recorder:
                 'text_bytes_per_step': self.bytes // max(steps, 1)}
 
 
-def measured_profile(config, ns, mod):
+def measured_profile(config, ns, mod, cycles_per_launch=1.0):
     """What the committed rocprofv3 PMC passes of this round say about nm_block_kernel on the preset's workload (profiles/,
     written by scripts/collect_pmc.py together with the commit they were taken at): HBM bytes per launch — FETCH_SIZE doubled
     as MI355X_MICROARCH.md prescribes for gfx950, KB units — and the share of SIMD cycles that issued VALU.  Empty for
-    workloads without a committed profile."""
+    workloads without a committed profile.  "Per launch" follows the line's own launch: the profile's bytes per cycle (its launch held
+    `_meta.cycles_per_launch` cycles) times the cycles one launch of THIS run held."""
     if config is None:
         return {}
     f = None
@@ -488,15 +500,16 @@ def measured_profile(config, ns, mod):
     meta = d.get('_meta', {})
     if meta.get('replicas') != ns or meta.get('mod') != mod:
         return {}
-    out = {'source': 'profiles/' + os.path.basename(f), 'commit': meta.get('commit')}
+    out = {'source': 'profiles/' + os.path.basename(f), 'commit': meta.get('commit'), 'kernel': meta.get('kernel')}
+    scale = cycles_per_launch / float(meta.get('cycles_per_launch') or 1)
     if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
-        out['traffic'] = (2.0 * d['FETCH_SIZE']['mean'] + d['WRITE_SIZE']['mean']) * 1024.0
+        out['traffic'] = (2.0 * d['FETCH_SIZE']['mean'] + d['WRITE_SIZE']['mean']) * 1024.0 * scale
         # min - max over the profiled launches and over the round's other profile runs of this preset (the cluster kernels' write-back of
         # hand-over lines moves the figure by up to 2x from run to run with unchanged kernels: quote a range, not a point)
-        lo = (2.0 * d['FETCH_SIZE']['min'] + d['WRITE_SIZE']['min']) * 1024.0
-        hi = (2.0 * d['FETCH_SIZE']['max'] + d['WRITE_SIZE']['max']) * 1024.0
-        for extra in meta.get('traffic_other_runs', []):
-            lo, hi = min(lo, extra), max(hi, extra)
+        lo = (2.0 * d['FETCH_SIZE']['min'] + d['WRITE_SIZE']['min']) * 1024.0 * scale
+        hi = (2.0 * d['FETCH_SIZE']['max'] + d['WRITE_SIZE']['max']) * 1024.0 * scale
+        for extra in meta.get('traffic_other_runs', []):          # recorded per cycle
+            lo, hi = min(lo, extra * cycles_per_launch), max(hi, extra * cycles_per_launch)
         out['traffic_range'] = [lo, hi]
     if 'SQ_ACTIVE_INST_VALU' in d and 'GRBM_GUI_ACTIVE' in d:
         # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs

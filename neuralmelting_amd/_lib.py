@@ -17,7 +17,7 @@ NM_THERMO_COLS, NM_TRACE_COLS, NM_STATS_COLS = 17, 4, 10
 # every symbol include/nm.h declares (tests check that the library exports all of them)
 SYMBOLS = ('nm_create', 'nm_destroy', 'nm_last_error', 'nm_create_note', 'nm_nslots', 'nm_natoms', 'nm_cus_per_replica', 'nm_heal_count', 'nm_get_const',
            'nm_get_slots', 'nm_set_slots', 'nm_snapshot', 'nm_snapshot_fetch',
-           'nm_set_state', 'nm_get_state', 'nm_init_lattice', 'nm_lattice_state', 'nm_set_thermo', 'nm_set_step', 'nm_run_md', 'nm_run_block', 'nm_get_thermo', 'nm_adapt',
+           'nm_set_state', 'nm_get_state', 'nm_init_lattice', 'nm_lattice_state', 'nm_set_thermo', 'nm_set_step', 'nm_run_md', 'nm_run_block', 'nm_run_cycles', 'nm_get_thermo', 'nm_adapt',
            'nm_exchange', 'nm_synchronize', 'nm_get_status', 'nm_format_thrm', 'nm_format_traj', 'nm_append_outputs', 'nm_timing_reset', 'nm_timing_get', 'nm_stats_get', 'nm_eval',
            'nm_set_rng_tape', 'nm_set_exchange_tape', 'nm_set_trace', 'nm_get_trace', 'nm_get_perm', 'nm_set_counters',
            'nm_get_exchange_crit')
@@ -70,6 +70,7 @@ def load():
     L.nm_lattice_state.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, C.c_uint32, C.c_int, C.c_double, C.c_int, c_double_p, c_double_p]
     L.nm_set_step.argtypes = [vp, C.c_uint32]
     L.nm_run_block.argtypes = [vp, C.c_int]
+    L.nm_run_cycles.argtypes = [vp, C.c_int, C.c_int]
     L.nm_run_md.argtypes = [vp, C.c_int]
     L.nm_get_thermo.argtypes = [vp, c_double_p]
     L.nm_adapt.argtypes = [vp]

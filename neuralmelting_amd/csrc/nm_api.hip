@@ -88,6 +88,7 @@ struct nm_ctx {
     bool use_order; // one workgroup per replica and more replicas than CUs: launch the slowest slots first (nm_order_kernel)
     unsigned int *d_census; // residency census of cluster launches (nm_kernels.h): the grid's counter, then one per cluster
     unsigned int census_base = 0, census_cbase = 0; // what those counters stand at (they only grow; reset_census zeroes both)
+    unsigned int *d_rowsync = nullptr; // nm_run_cycles: per local row an arrival counter and a release word, then the abort word (KParams::rowbar, rowgo, cyc_abort)
     bool over;              // the grid holds twice the clusters the chip does at once (pick_q)
     // Calls queued on the stream since the host last looked at the outcome (settle): if a block of them stopped because its
     // cluster grid was not resident or a hand-over timed out, nothing after it has run (KParams::halt) and the same calls are
@@ -229,6 +230,37 @@ int blocks_per_cu()
     return n;
 }
 
+template <class C>
+hipError_t launch_cycles(const nm_ctx *c, const KParams &p)
+{
+    hipError_t e = hipFuncSetAttribute((const void *)nm_cycles_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(nm_cycles_kernel<C>, dim3(nm_grid(c->nslots, c->cus)), dim3(C::BLOCK), C::LDS_BYTES, c->stream, p);
+    return hipGetLastError();
+}
+
+// nm_cycles_kernel is instantiated for the 4^3 clusters (LJ and Al) and the 6^3 cluster of eight.  nm_run_cycles uses it only when asked to
+// (NM_FUSED_CYCLES=1: the 4^3 clusters of 2 and 4; =all: every instantiation): measured on the 8 x 8 grid, rows that do not wait for one another are
+// worth ~3 % of a launch, and the block's code, compiled inside the loop over cycles, comes out ~3 % slower (three times the vector spills of
+// nm_block_kernel) — net -0.1 to +1.0 % at 2 and 4 workgroups per replica, -2 to -5 % at 8.  The default is the loop of single launches.
+bool cycles_kind_built(const nm_ctx *c) { return (c->kind == 0 && c->cus >= 2) || (c->kind == 1 && c->cus == 8); }
+bool cycles_kind_ok(const nm_ctx *c)
+{
+    const char *e = std::getenv("NM_FUSED_CYCLES");
+    if (!e || !cycles_kind_built(c)) return false;
+    if (!std::strcmp(e, "all")) return true;
+    return !std::strcmp(e, "1") && c->kind == 0 && (c->cus == 2 || c->cus == 4);
+}
+
+hipError_t launch_cycles_kind(const nm_ctx *c, const KParams &p)
+{
+    if (c->kind == 0) {
+        if (c->pot == 1) return c->cus == 4 ? launch_cycles<CfgSmallSCQ4>(c, p) : launch_cycles<CfgSmallSCQ2>(c, p);
+        return c->cus == 8 ? launch_cycles<CfgSmallQ8>(c, p) : c->cus == 4 ? launch_cycles<CfgSmallQ4>(c, p) : launch_cycles<CfgSmallQ2>(c, p);
+    }
+    return launch_cycles<CfgMidQ8>(c, p);
+}
+
 hipError_t launch_kind(const nm_ctx *c, const KParams &p)
 {
     switch (c->kind) {
@@ -287,7 +319,7 @@ std::string status_text(const nm_ctx *c, int k, int bits)
     return buf;
 }
 
-enum : int { OP_BLOCK = 0, OP_ADAPT = 1, OP_EXCHANGE = 2, OP_MD = 3 };
+enum : int { OP_BLOCK = 0, OP_ADAPT = 1, OP_EXCHANGE = 2, OP_MD = 3, OP_CYCLES = 4 }; // OP_CYCLES: arg = MOD, trace = number of cycles
 
 // ---- the queued calls (nm_run_block, nm_run_md, nm_adapt, nm_exchange) as stream operations; issued by the API call and, after a
 // block had to be given up, again by settle()
@@ -368,6 +400,55 @@ int issue_exchange(nm_ctx *c, uint32_t step)
                        c->xtape_n ? c->d_xtape : nullptr, c->d_xcrit, c->d_nswaps, c->d_halt);
     HIPCHK(c, hipGetLastError());
     c->journal.push_back({ OP_EXCHANGE, 0, 0, step, 0u });
+    return NM_OK;
+}
+
+// nm_run_cycles as stream operations: ONE launch of nm_cycles_kernel where the configuration has one and the whole grid is resident and checked by the
+// census (clusters), else the same cycles as single blocks, adapts and exchanges
+int issue_cycles(nm_ctx *c, int ncycles, int mod, uint32_t step, bool timed)
+{
+    const bool fused = c->whole_rows && c->cus > 1 && !c->over && cycles_kind_ok(c) && !c->d_tape && !c->xtape_n && !c->trace_on &&
+                       !(c->use_order && (c->cus == 1 || c->over));
+    if (!fused) {
+        for (int k = 0; k < ncycles; ++k) {
+            int rc = issue_block(c, OP_BLOCK, mod, step + (uint32_t)k, 0, nullptr, timed);
+            if (!rc) rc = issue_adapt(c);
+            if (!rc) rc = issue_exchange(c, step + (uint32_t)k);
+            if (rc) return rc;
+        }
+        return NM_OK;
+    }
+    const int nrows = c->cfg.nrows;
+    if (!c->d_rowsync) HIPCHK(c, dalloc(&c->d_rowsync, (size_t)2 * nrows + 2));
+    HIPCHK(c, hipMemsetAsync(c->d_rowsync, 0, sizeof(unsigned int) * ((size_t)2 * nrows + 2), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_nswaps, 0, sizeof(int), c->stream));
+    const uint32_t first_id = c->launch_id + 1;
+    c->launch_id += (uint32_t)ncycles;   // one id per cycle: the hand-over granules of successive blocks must differ
+    KParams p;
+    const uint32_t keep = c->step;
+    c->step = step;
+    fill_params(c, p);
+    c->step = keep;
+    p.launch_id = first_id;
+    p.mod = mod; p.ncycles = ncycles; p.nt = c->cfg.nt; p.row0 = c->cfg.row0;
+    p.rowbar = c->d_rowsync; p.rowgo = c->d_rowsync + nrows; p.cyc_abort = (int *)(c->d_rowsync + 2 * nrows); p.nswaps = c->d_nswaps;
+    p.order = nullptr; p.tape = nullptr; p.trace = nullptr;
+    if (testing())
+        if (const char *e = std::getenv("NM_INJECT_CENSUS"))
+            if (std::atoi(e) == c->cluster_launches) p.inj_census = 1;
+    ++c->cluster_launches;
+    if (c->census_base > 0x3F000000u || c->census_cbase > 0x3F000000u) { HIPCHK(c, reset_census(c)); fill_census(c, p); }
+    if (timed) {
+        EvPair &e = c->ev[c->ev_next];
+        harvest(c, e);
+        HIPCHK(c, hipEventRecord(e.a, c->stream));
+        HIPCHK(c, launch_cycles_kind(c, p));
+        HIPCHK(c, hipEventRecord(e.b, c->stream));
+        e.used = true; e.launch_id = first_id;
+        c->ev_next = (c->ev_next + 1) % (int)c->ev.size();
+    } else HIPCHK(c, launch_cycles_kind(c, p));
+    census_advance(c);
+    c->journal.push_back({ OP_CYCLES, mod, ncycles, step, first_id });
     return NM_OK;
 }
 
@@ -474,9 +555,15 @@ int settle(nm_ctx *c)
         if (!halt && !any) { c->journal.clear(); c->err.clear(); return NM_OK; } // (nm_last_error is empty after a call that returned NM_OK)
         const int healable = ST_NOT_RESIDENT | ST_SYNC_TIMEOUT;
         size_t at = c->journal.size();
-        for (size_t k = 0; k < c->journal.size(); ++k)
-            if ((c->journal[k].kind == OP_BLOCK || c->journal[k].kind == OP_MD) && (int)c->journal[k].launch_id == halt) { at = k; break; }
-        if (halt && !(any & ~healable) && c->cus > 1 && at < c->journal.size()) {
+        bool mid_cycles = false; // the halt lies inside a launch of several cycles, behind its first: rows are at different cycles, nothing to re-issue
+        for (size_t k = 0; k < c->journal.size(); ++k) {
+            const nm_ctx::Op &o = c->journal[k];
+            if ((o.kind == OP_BLOCK || o.kind == OP_MD) && (int)o.launch_id == halt) { at = k; break; }
+            if (o.kind == OP_CYCLES && (uint32_t)halt >= o.launch_id && (uint32_t)halt < o.launch_id + (uint32_t)o.trace) {
+                at = k; mid_cycles = (uint32_t)halt != o.launch_id || (any & ST_SYNC_TIMEOUT); break;
+            }
+        }
+        if (halt && !(any & ~healable) && c->cus > 1 && at < c->journal.size() && !mid_cycles) {
             // ---- re-issue at a lower Q
             const int q_old = c->cus;
             std::string why;
@@ -505,6 +592,7 @@ int settle(nm_ctx *c)
             for (size_t k = 0; k < todo.size(); ++k) {
                 const nm_ctx::Op &o = todo[k];
                 if (o.kind == OP_BLOCK || o.kind == OP_MD) rc = issue_block(c, o.kind, o.arg, o.step, o.trace, k == 0 ? c->d_rerun : nullptr, o.kind == OP_BLOCK);
+                else if (o.kind == OP_CYCLES) rc = issue_cycles(c, o.trace, o.arg, o.step, true); // (its census failed: nothing had run)
                 else if (o.kind == OP_ADAPT) rc = issue_adapt(c);
                 else rc = issue_exchange(c, o.step);
                 if (rc) return rc;
@@ -538,7 +626,7 @@ void free_ctx(nm_ctx *c)
     void *ptrs[] = { c->d_x, c->d_v, c->d_box, c->d_steps, c->d_therm, c->d_count, c->d_ratio, c->d_et, c->d_pf, c->d_tq,
                      c->d_stats, c->d_slot2buf, c->d_status, c->d_nswaps, c->d_evalU, c->d_evalW, c->d_evalF, c->d_xcrit,
                      c->d_xtape, c->d_tape, c->d_tape_off, c->d_trace, c->d_nbr, c->d_aux, c->d_prof, c->d_tline, c->d_xbuf, c->d_census,
-                     c->d_status_acc, c->d_halt, c->d_rerun, c->d_order, c->d_last_ticks };
+                     c->d_status_acc, c->d_halt, c->d_rerun, c->d_order, c->d_last_ticks, c->d_rowsync };
     for (void *q : ptrs) if (q) hipFree(q);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->side) hipStreamSynchronize(c->side);
@@ -1086,6 +1174,14 @@ int nm_run_md(nm_ctx *c, int nsteps)
     if (!c || nsteps < 1) return fail(c, NM_ERR_ARG, "nm_run_md: bad argument");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     return issue_block(c, OP_MD, nsteps, c->step, 0, nullptr, false);
+}
+
+int nm_run_cycles(nm_ctx *c, int ncycles, int mod)
+{
+    if (!c || ncycles < 1 || mod < 0) return fail(c, NM_ERR_ARG, "nm_run_cycles: bad argument");
+    if (!c->whole_rows) return fail(c, NM_ERR_UNSUPPORTED, "nm_run_cycles: this context holds a partial pressure row (the exchange spans contexts)");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    return issue_cycles(c, ncycles, mod, c->step, true);
 }
 
 int nm_get_thermo(nm_ctx *c, double *rows)

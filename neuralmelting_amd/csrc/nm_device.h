@@ -64,6 +64,12 @@ struct KParams {
     const int *order;              // one workgroup per replica and more replicas than the chip holds at once: workgroup b runs slot order[b],
                                    // slowest first (by the time each slot's previous block took); null = identity
     unsigned long long *last_ticks; // per slot: duration of its last block (100 MHz ticks), what nm_order_kernel sorts by
+    // nm_run_cycles (nm_cycles_kernel): several cycles of block / adapt / exchange in ONE launch; the replicas of a pressure row meet at the end of
+    // every block, the rows never wait for one another
+    int ncycles, nt, row0;         // cycles of this launch; temperatures per row; global index of the context's first row
+    unsigned int *rowbar, *rowgo;  // per local row: workgroups arrived (monotonic within the launch), cycles released by the row's leader
+    int *cyc_abort;                // set by whoever leaves the launch early: nobody waits for a row that will not complete
+    int *nswaps;                   // accepted swaps of the launch (atomic)
 };
 
 // status bits reach the host through status[] (last launch) and status_acc[] (everything since the host last looked); a block

@@ -2360,8 +2360,11 @@ enum : int { PH_INIT = 0, PH_BULK = 1, PH_VMC = 2, PH_HMC_START = 3, PH_HMC_STEP
 #else
 #define NM_MIN_WAVES
 #endif
+// The block of one workgroup: returns 0 when the replica's block completed and was stored, 1 when this workgroup had nothing to run (halted
+// queue, padding workgroup, a slot the re-issue mask leaves out, nm_eval), 2 when the block stopped on an error (reported; state untouched).
+// `first`: the launch's residency census is taken (nm_cycles_kernel takes it in its first cycle only).
 template <class C>
-__global__ void __launch_bounds__(C::BLOCK NM_MIN_WAVES) nm_block_kernel(const KParams p)
+__device__ __forceinline__ int nm_block_body(const KParams &p, bool first)
 {
     constexpr int BLOCK = C::BLOCK;
     const unsigned long long t_entry = wall_clock64(); // (stats column 4)
@@ -2373,10 +2376,10 @@ __global__ void __launch_bounds__(C::BLOCK NM_MIN_WAVES) nm_block_kernel(const K
     const int r_ = b >> 3, qq = r_ % Q;
     const int cluster = (b & 7) + 8 * (r_ / Q);    // (Q = 1: b itself)
     const int slot = (p.order && cluster < p.nslots) ? p.order[cluster] : cluster; // order: the replicas with the longest blocks first
-    if (halted(p)) return; // an earlier block stopped on an error: nothing runs on its state until the host has dealt with it
+    if (halted(p)) return 1; // an earlier block stopped on an error: nothing runs on its state until the host has dealt with it
     if (slot >= p.nslots) { // padding workgroup
-        if (Q > 1 && p.census && !p.over) (void)residency_census<C>(p, cluster);
-        return;
+        if (first && Q > 1 && p.census && !p.over) (void)residency_census<C>(p, cluster);
+        return 1;
     }
     const int buf = p.slot2buf[slot];
     const int tid = threadIdx.x;
@@ -2388,11 +2391,11 @@ __global__ void __launch_bounds__(C::BLOCK NM_MIN_WAVES) nm_block_kernel(const K
     // armed has returned above and leaves the failed block's bits where they are.
     if (writer && !(p.rerun_mask && !p.rerun_mask[slot])) p.status[slot] = 0;
 
-    if (Q > 1 && p.census && !residency_census<C>(p, cluster)) { // nothing has been touched yet
+    if (first && Q > 1 && p.census && !residency_census<C>(p, cluster)) { // nothing has been touched yet
         if (writer) report_status(p, slot, ST_NOT_RESIDENT, true);
-        return;
+        return 2;
     }
-    if (p.rerun_mask && !p.rerun_mask[slot]) return; // re-issue of a block: this replica completed it the first time
+    if (p.rerun_mask && !p.rerun_mask[slot]) return 1; // re-issue of a block: this replica completed it the first time
     // Which XCD is this workgroup on?  HIP promises no placement; blockIdx % 8 is only the observed round-robin.  The members of a
     // cluster exchange their XCC ids once per block (write-through granules, valid anywhere): sum and sum of squares over the Q
     // members tell every member, identically, whether all ids are equal (Q sum(id^2) == (sum id)^2).
@@ -2470,7 +2473,7 @@ __global__ void __launch_bounds__(C::BLOCK NM_MIN_WAVES) nm_block_kernel(const K
                         const int i = a / 3, c = a - 3 * i;
                         p.evalF[(size_t)slot * 3 * N + a] = (c == 0 ? R.fx : c == 1 ? R.fy : R.fz)[i];
                     }
-                return;
+                return 1;
             }
         } else if (phase == PH_ITER_END) { // iter_position_mc of the EAM: U, W of the final configuration are in (the reference's last `run 0`)
             if (p.trace && writer) {
@@ -2629,7 +2632,7 @@ __global__ void __launch_bounds__(C::BLOCK NM_MIN_WAVES) nm_block_kernel(const K
     // re-issue the block.
     if (R.status & fatal) {
         if (writer) report_status(p, slot, R.status, true);
-        return;
+        return 2;
     }
     R.store(buf);
     { // the longest list row any workgroup of the replica built (stats column 8; positive doubles order like their bit patterns)
@@ -2670,6 +2673,13 @@ __global__ void __launch_bounds__(C::BLOCK NM_MIN_WAVES) nm_block_kernel(const K
         if (p.prof) for (int q = 0; q < NM_PROF_SLOTS; ++q) p.prof[(size_t)slot * NM_PROF_SLOTS + q] += R.prof_acc[q];
 #endif
     }
+    return 0;
+}
+
+template <class C>
+__global__ void __launch_bounds__(C::BLOCK NM_MIN_WAVES) nm_block_kernel(const KParams p)
+{
+    (void)nm_block_body<C>(p, true);
 }
 
 // Launch order for grids with more one-workgroup replicas than the chip holds at once (the reference's run.sh setting: 1024 replicas
@@ -2708,11 +2718,9 @@ __global__ void nm_snapshot_kernel(const SnapArgs a)
     for (size_t i = t; i < a.n[6]; i += nt) mi[i] = a.slot2buf[i];
 }
 
-// gen_mc_param (remcmc:726-745): one thread per slot
-__global__ void nm_adapt_kernel(int nslots, const int *slot2buf, double *steps, double *count, float *ratio, const int *halt)
+// gen_mc_param (remcmc:726-745) of one slot
+__device__ __forceinline__ void adapt_slot(int k, const int *slot2buf, double *steps, double *count, float *ratio)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nslots || (halt && *halt)) return; // (a block stopped on an error: its successors wait for the host, nm_api.hip settle)
     const int b = slot2buf[k];
     for (int c = 0; c < 3; ++c) {
         const float a = ratio[3 * k + c];
@@ -2725,6 +2733,184 @@ __global__ void nm_adapt_kernel(int nslots, const int *slot2buf, double *steps, 
     for (int c = 0; c < 6; ++c) count[6 * k + c] = 0.0;
 }
 
+// replica_exchange (remcmc:776-803) of one local pressure row r; returns the accepted swaps
+__device__ __forceinline__ int exchange_row(int r, int nt, int row0, uint32_t seed, uint32_t step, int *slot2buf, const double *therm, const double *et,
+                                            const double *pf, const double *tape, double *crit_out)
+{
+    const int ppr = nt * (nt - 1) / 2;
+    int q = 0, sw = 0;
+    for (int vv = nt - 1; vv >= 0; --vv)
+        for (int w = 0; w < vv; ++w, ++q) {
+            const int i = r * nt + vv, j = r * nt + w;
+            const int bi = slot2buf[i], bj = slot2buf[j];
+            const double de = (therm[5 * bi + 1] + therm[5 * bi + 2]) - (therm[5 * bj + 1] + therm[5 * bj + 2]);
+            const double dvol = therm[5 * bi + 4] - therm[5 * bj + 4];
+            const double dh = de * (1.0 / et[i] - 1.0 / et[j]) + (pf[i] - pf[j]) * dvol;
+            double u;
+            if (tape) u = tape[r * ppr + q];
+            else {
+                uint32_t o[4];
+                philox4x32_10((uint32_t)((row0 + r) * ppr + q), S_EXCH, 0u, step, seed, 0xFFFFFFFFu, o);
+                u = u01(o[0], o[1]);
+            }
+            if (crit_out) crit_out[r * ppr + q] = dh;
+            const double e = exp(dh);
+            const double mm = (e != e) ? e : (e < 1.0 ? e : 1.0);
+            if (u <= mm) { slot2buf[i] = bj; slot2buf[j] = bi; ++sw; }
+        }
+    return sw;
+}
+
+// nm_run_cycles: `ncycles` cycles of the reference's main loop with outputs off (remcmc:977-995: gen_samples, gen_mc_params, replica_exchange) in
+// ONE launch.  A cycle's block is nm_block_body as in nm_block_kernel; behind it the workgroups of a pressure ROW meet (every workgroup signs in on
+// the row's counter with an agent-scope release, so that its stores — positions, velocities, thermo scalars, counters — are out of its XCD's L2), the
+// row's leader (workgroup 0 of the row's first replica, thread 0) adapts the row's step sizes and runs the row's exchange sweep exactly as
+// nm_adapt_kernel and nm_exchange_kernel do, and releases the row into its next cycle (agent-scope acquire in every wave: stale lines of the other
+// XCDs' writes are dropped).  Rows never wait for one another — the exchange never leaves a row (remcmc:782-798) — so a launch of K cycles lasts as
+// long as its slowest ROW's K blocks, not K times the slowest replica of the grid: the number of trajectories a block draws is Binomial(128, 3/4),
+// i.e. a block's time scatters by 3.5 %, and a launch of 64 replicas waited for the slowest of 64 at every cycle.  Spins are bounded (2 s) and leave
+// through cyc_abort, which also whoever stops on an error sets: nobody waits for a row that will not complete.  Requires whole rows, no launch
+// order table, no tapes, no trace (nm_api.hip nm_run_cycles falls back to single cycles otherwise).
+template <class C>
+__global__ void __launch_bounds__(C::BLOCK NM_MIN_WAVES) nm_cycles_kernel(const KParams p0)
+{
+    const int ncycles = p0.ncycles, nt = p0.nt;
+    const uint32_t step0 = p0.step, id0 = p0.launch_id;
+    const int Q = p0.cus, b = blockIdx.x;
+    const int r_ = b >> 3, qq = r_ % Q;
+    const int slot = (b & 7) + 8 * (r_ / Q); // (nm_block_body's mapping, without a launch-order table)
+    const int tid = threadIdx.x;
+    const bool real = slot < p0.nslots;
+    const int row = real ? slot / nt : 0;
+    const bool leader_wg = real && qq == 0 && slot == row * nt; // the workgroup that adapts and exchanges for its row
+    const unsigned int per_cycle = (unsigned int)(nt * Q); // workgroups of a row
+#pragma clang loop unroll(disable)
+    for (int cyc = 0; cyc < ncycles; ++cyc) {
+        // the parameters are fetched from the kernel's argument segment anew in every cycle: held across the loop they would occupy ~150 scalar registers
+        // for the whole block and spill twice what nm_block_kernel spills
+        typedef const KParams __attribute__((address_space(4))) *kparams_ptr;
+        kparams_ptr kp = (kparams_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        KParams pc = *(const KParams *)kp;
+        const KParams &p = pc;                       // (this cycle's copy)
+        pc.step = step0 + (uint32_t)cyc;
+        pc.launch_id = id0 + (uint32_t)cyc; // (distinguishes the hand-over granules of successive blocks)
+        int first = cyc == 0;                        // (opaque: the compiler would peel the first cycle off the loop, a second copy of the whole block)
+        asm volatile("" : "+v"(first));
+        const int rc = nm_block_body<C>(pc, __builtin_amdgcn_readfirstlane(first) != 0);
+        if (!real) return;                           // padding workgroups took part in the census and leave
+        if (rc != 0) {                               // stopped (or nothing to run): the rows must not wait for this workgroup
+            if (tid == 0) __hip_atomic_store(p.cyc_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        __syncthreads();                             // every thread's stores of this block are issued
+        int abort_ = 0;
+        volatile int *const flag = (volatile int *)(nm_lds + C::OFF_RED);
+        unsigned long long t0 = 0;
+        if (tid == 0) {
+            (void)__hip_atomic_fetch_add(p.rowbar + row, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            t0 = wall_clock64();
+        }
+        if (leader_wg) {
+            // ---- the row's leader workgroup: wait for the row, then gen_mc_params and replica_exchange of the row.  The sweep itself is
+            // sequential (later pairs see earlier swaps), but nothing around it is: the row's energies, volumes and constants and the sweep's
+            // uniforms are fetched / drawn by the workgroup's threads side by side into LDS (the block's arrays are dead by now), ONE thread
+            // then walks the pairs on those (a single thread doing it all on global memory kept the row's CUs waiting ~0.1 ms per cycle)
+            if (tid == 0) {
+                const unsigned int want = (unsigned int)(cyc + 1) * per_cycle;
+                for (;;) {
+                    if (__hip_atomic_load(p.rowbar + row, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+                    if (__hip_atomic_load(p.cyc_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { abort_ = 1; break; }
+                    if (wall_clock64() - t0 > 200000000ull) { // 2 s: a workgroup of the row never arrived
+                        abort_ = 1; __hip_atomic_store(p.cyc_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        report_status(pc, slot, ST_SYNC_TIMEOUT, true);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                *flag = abort_;
+            }
+            __syncthreads();
+            abort_ = *flag;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();
+            if (!abort_) {
+                const int ppr = nt * (nt - 1) / 2, k0 = row * nt;
+                double *const E = (double *)(nm_lds + C::OFF_POS), *const V = E + nt, *const IE = V + nt, *const PF = IE + nt, *const Uu = PF + nt;
+                int *const Bf = (int *)(Uu + ppr);
+                for (int l = tid; l < nt; l += C::BLOCK) {
+                    const int bq = p.slot2buf[k0 + l];
+                    E[l] = p.therm[5 * bq + 1] + p.therm[5 * bq + 2]; V[l] = p.therm[5 * bq + 4];
+                    IE[l] = 1.0 / p.et[k0 + l]; PF[l] = p.pf[k0 + l]; Bf[l] = bq;
+                }
+                for (int l = tid; l < ppr; l += C::BLOCK) {
+                    uint32_t o[4];
+                    philox4x32_10((uint32_t)((p.row0 + row) * ppr + l), S_EXCH, 0u, pc.step, p.seed, 0xFFFFFFFFu, o);
+                    Uu[l] = u01(o[0], o[1]);
+                }
+                for (int l = tid; l < 3 * nt; l += C::BLOCK) { // gen_mc_param (adapt_slot), one (slot, step size) per thread
+                    const int k = k0 + l / 3, c3 = l % 3, bq = p.slot2buf[k];
+                    const float a = p.ratio[3 * k + c3];
+                    double sz = p.steps[3 * bq + c3];
+                    if (a < 0.5f) sz = 0.9375 * sz;
+                    if (a > 0.5f) sz = 1.0625 * sz;
+                    p.steps[3 * bq + c3] = sz;
+                    p.ratio[3 * k + c3] = 0.0f;
+                }
+                for (int l = tid; l < 6 * nt; l += C::BLOCK) p.count[6 * k0 + l] = 0.0;
+                __syncthreads();
+                if (tid == 0) { // the sweep of exchange_row on the row's copies: the same differences, the same uniforms, the same decisions
+                    int q = 0, sw = 0;
+                    for (int vv = nt - 1; vv >= 0; --vv)
+                        for (int w = 0; w < vv; ++w, ++q) {
+                            const double dh = (E[vv] - E[w]) * (IE[vv] - IE[w]) + (PF[vv] - PF[w]) * (V[vv] - V[w]);
+                            const double e = exp(dh);
+                            const double mm = (e != e) ? e : (e < 1.0 ? e : 1.0);
+                            if (Uu[q] <= mm) {
+                                const double te = E[vv], tv = V[vv]; const int tb = Bf[vv];
+                                E[vv] = E[w]; V[vv] = V[w]; Bf[vv] = Bf[w];
+                                E[w] = te; V[w] = tv; Bf[w] = tb;
+                                ++sw;
+                            }
+                        }
+                    if (sw && p.nswaps) atomicAdd(p.nswaps, sw);
+                }
+                __syncthreads();
+                for (int l = tid; l < nt; l += C::BLOCK) const_cast<int *>(p.slot2buf)[k0 + l] = Bf[l];
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(p.rowgo + row, (unsigned int)(cyc + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (tid == 0) {
+            if (!abort_)
+                for (;;) {
+                    if (__hip_atomic_load(p.rowgo + row, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)(cyc + 1)) break;
+                    if (__hip_atomic_load(p.cyc_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { abort_ = 1; break; }
+                    if (wall_clock64() - t0 > 400000000ull) { // 4 s: the row's leader never released the row
+                        abort_ = 1; __hip_atomic_store(p.cyc_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        report_status(pc, slot, ST_SYNC_TIMEOUT, true);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            *flag = abort_;
+        }
+        __syncthreads();
+        const int ab = *(volatile int *)(nm_lds + C::OFF_RED);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // every wave: what the other XCDs wrote is re-read, not found stale in this one's caches
+        __syncthreads();                                    // (the word in LDS is free again before the next block's reductions use it)
+        if (ab) return;
+    }
+}
+
+// gen_mc_param (remcmc:726-745): one thread per slot
+__global__ void nm_adapt_kernel(int nslots, const int *slot2buf, double *steps, double *count, float *ratio, const int *halt)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nslots || (halt && *halt)) return; // (a block stopped on an error: its successors wait for the host, nm_api.hip settle)
+    adapt_slot(k, slot2buf, steps, count, ratio);
+}
+
 // replica_exchange (remcmc:776-803): rows are independent, the sweep inside a row is strictly sequential.
 // A swap exchanges entries [0..11] of the two state lists = configuration, thermo scalars and dx,dv,dt; here
 // that is one swap of slot->buffer labels, no coordinate moves.
@@ -2735,30 +2921,8 @@ __global__ void __launch_bounds__(64) nm_exchange_kernel(int nrows, int nt, int 
     // ONE wave: rows r = lane, lane + 64, ...; the swap count is summed over the wave and stored (it used to be an atomicAdd onto a
     // word zeroed by a memset in front of every launch: one more dependent stream operation per cycle)
     if (halt && *halt) return;
-    const int ppr = nt * (nt - 1) / 2;
     int sw = 0;
-    for (int r = threadIdx.x; r < nrows; r += 64) {
-        int q = 0;
-        for (int vv = nt - 1; vv >= 0; --vv)
-            for (int w = 0; w < vv; ++w, ++q) {
-                const int i = r * nt + vv, j = r * nt + w;
-                const int bi = slot2buf[i], bj = slot2buf[j];
-                const double de = (therm[5 * bi + 1] + therm[5 * bi + 2]) - (therm[5 * bj + 1] + therm[5 * bj + 2]);
-                const double dvol = therm[5 * bi + 4] - therm[5 * bj + 4];
-                const double dh = de * (1.0 / et[i] - 1.0 / et[j]) + (pf[i] - pf[j]) * dvol;
-                double u;
-                if (tape) u = tape[r * ppr + q];
-                else {
-                    uint32_t o[4];
-                    philox4x32_10((uint32_t)((row0 + r) * ppr + q), S_EXCH, 0u, step, seed, 0xFFFFFFFFu, o);
-                    u = u01(o[0], o[1]);
-                }
-                if (crit_out) crit_out[r * ppr + q] = dh;
-                const double e = exp(dh);
-                const double mm = (e != e) ? e : (e < 1.0 ? e : 1.0);
-                if (u <= mm) { slot2buf[i] = bj; slot2buf[j] = bi; ++sw; }
-            }
-    }
+    for (int r = threadIdx.x; r < nrows; r += 64) sw += exchange_row(r, nt, row0, seed, step, slot2buf, therm, et, pf, tape, crit_out);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) sw += __shfl_xor(sw, d, 64);
     if (threadIdx.x == 0) *nswaps = sw;

@@ -161,6 +161,11 @@ class Engine:
         """gen_samples (remcmc:694-719): MOD moves for every replica, asynchronous"""
         self._chk(self.lib.nm_run_block(self.h, int(mod)))
 
+    def run_cycles(self, ncycles, mod):
+        """ncycles x (gen_samples, gen_mc_params, replica_exchange) with outputs off, steps STEP .. STEP + ncycles - 1 (nm_run_cycles): one launch in
+        which only the replicas of a pressure row wait for one another, where the configuration has the kernel for it; the same chains either way"""
+        self._chk(self.lib.nm_run_cycles(self.h, int(ncycles), int(mod)))
+
     def run_md(self, nsteps):
         """init_sample's -is dynamics (remcmc:421-425): velocities at T, then nsteps of NVE"""
         self._chk(self.lib.nm_run_md(self.h, int(nsteps)))

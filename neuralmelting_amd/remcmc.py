@@ -327,6 +327,18 @@ class Run:
         return Engine(self.natoms, self.P, self.T, element=self.EL, ppos=self.PPOS, pvol=self.PVOL, nstps=self.NSTPS,
                       bulk=self.BM, seed=SEED, device=self.device, iter_revert=self.ITER_REVERT, **kw)
 
+    def _quiet_cycles(self):
+        """how many cycles from STEP on neither record (remcmc:983-985), nor dump the restart file (remcmc:990-992), nor are the run's last
+        (remcmc:994-995: no exchange behind it) — those can go to the engine as one call (Engine.run_cycles); 0 where a pressure row
+        is split across ranks (its exchange needs the host)"""
+        if getattr(self, 'split_rows', False) or not hasattr(self.engine, 'run_cycles'):
+            return 0
+        n, s = 0, self.STEP
+        while (s + 1) <= self.CUTOFF and (s + 1) % self.REFREQ != 0 and (s + 1) != self.NSMPL:
+            n += 1
+            s += 1
+        return n
+
     def replica_exchange(self, step):
         """replica_exchange (remcmc:776-803): on the device when this rank owns whole rows, else all-gather + identical sweep"""
         eng = self.engine
@@ -390,8 +402,16 @@ class Run:
         # block runs on the GPU — the stream never waits for the copies, the formatting or the files
         eng.synchronize()
         t_loop = time.perf_counter()
-        for self.STEP in range(self.NSMPL):
+        self.STEP = 0
+        while self.STEP < self.NSMPL:
             eng.set_step(self.STEP)
+            quiet = self._quiet_cycles()
+            if quiet > 1:                                 # cycles that write nothing and dump nothing: one call, one launch where the
+                eng.run_cycles(quiet, self.MOD)           # grid has the kernel for it (nm_run_cycles) — the same chains
+                if self.VERBOSE:
+                    self.log('cycles %d-%d: outputs off' % (self.STEP, self.STEP + quiet - 1))
+                self.STEP += quiet
+                continue
             eng.run_block(self.MOD)                       # gen_samples (asynchronous)
             record = (self.STEP + 1) > self.CUTOFF        # remcmc:983-985
             if record:
@@ -407,6 +427,8 @@ class Run:
             while snaps > (1 if record else 0):           # the cycle before this one: write_outputs (remcmc:259-286), in cycle order
                 self._write_async(*eng.snapshot_fetch())
                 snaps -= 1
+            self.STEP += 1
+        self.STEP = self.NSMPL - 1
         while snaps:
             self._write_async(*eng.snapshot_fetch())
             snaps -= 1

@@ -9,6 +9,11 @@ RND = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith('-') else 
 WRITE = '--write' in sys.argv
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
+def kpc(o):
+    """kernel ms per CYCLE: a launch of nm_cycles_kernel holds `cycles_per_launch` of them"""
+    return o['kernel_avg_ms'] / (o.get('cycles_per_launch') or 1)
+
+
 D = {}
 for f in ['C2', 'driver', 'C3', 'C4', 'C5', 'C5x2', 'runsh', 'C1', 'C2_iter', 'C2_rows4', 'C2_rows2', 'C2_rows1', 'C2_record', 'C5_record']:
     g = 'gpurun_out/final_%s/bench_%s.json' % (RND, f)
@@ -18,18 +23,21 @@ PM = {}
 for t in ['C2', 'C3', 'C4', 'C5', 'runsh']:
     d = json.load(open('profiles/%s_pmc_block_kernel_%s.json' % (RND, t)))
     cyc = d['GRBM_GUI_ACTIVE']['mean'] / 8
-    r = list(csv.reader(open('profiles/%s_kernel_stats_%s.csv' % (RND, t))))
-    PM[t] = dict(traffic=(2 * d['FETCH_SIZE']['mean'] + d['WRITE_SIZE']['mean']) * 1024, valu=4 * d['SQ_ACTIVE_INST_VALU']['mean'] / (256 * 4 * cyc),
+    kname = d['_meta'].get('kernel') or 'nm_block_kernel'
+    cpl = d['_meta'].get('cycles_per_launch') or 1          # everything below is per CYCLE (one block of MOD moves per replica)
+    r = [x for x in csv.reader(open('profiles/%s_kernel_stats_%s.csv' % (RND, t))) if x and kname in x[0]] or [[kname, '0', '0', '0']]
+    r = [None] + r
+    PM[t] = dict(traffic=(2 * d['FETCH_SIZE']['mean'] + d['WRITE_SIZE']['mean']) * 1024 / cpl, valu=4 * d['SQ_ACTIVE_INST_VALU']['mean'] / (256 * 4 * cyc),
                  conf=d['SQ_LDS_BANK_CONFLICT']['mean'] / d['SQ_ACTIVE_INST_LDS']['mean'], wait=d['SQ_WAIT_ANY']['mean'] / d['SQ_WAVE_CYCLES']['mean'],
-                 all_ms=float(r[1][3]) / 1e6, commit=d['_meta']['commit'], other=d['_meta'].get('traffic_other_runs', []),
-                 fetch=d['FETCH_SIZE']['mean'] / 1024, write=d['WRITE_SIZE']['mean'] / 1024)
+                 all_ms=float(r[1][3]) / 1e6 / cpl, kernel=kname, commit=d['_meta']['commit'], other=d['_meta'].get('traffic_other_runs', []),
+                 fetch=d['FETCH_SIZE']['mean'] / 1024 / cpl, write=d['WRITE_SIZE']['mean'] / 1024 / cpl)
 
 if not WRITE:
     for f, d in D.items():
         cb = d.get('cpu_baseline') or {}
         r = d['roofline']
         print('%-9s sustained %9.0f (%.2f ms) window %9.0f (%.2f ms) frac %.4f / exec %.4f / window %.4f  %.2f TF  alg %.1f GB/s  rb %.2f  cpu %s / %s  x%s  Q=%d prof %s'
-              % (f, d['value'], r['kernel_avg_ms'], d['window']['value'], d['window']['kernel_avg_ms'], r['frac'], r['frac_executed'], d['window']['frac'], r['achieved'],
+              % (f, d['value'], kpc(r), d['window']['value'], kpc(d['window']), r['frac'], r['frac_executed'], d['window']['frac'], r['achieved'],
                  (d.get('roofline_hbm') or {}).get('achieved', 0), r['list_rebuilds_per_sweep'], '%.0f' % cb['value'] if cb else '-',
                  '%.0f' % cb['single_thread']['value'] if cb else '-', '%.0f' % (d['value'] / cb['value']) if cb else '-', r['cus_per_replica'], r.get('profile_commit')))
     for t, m in PM.items():
@@ -72,8 +80,8 @@ def design_rows():
     rows = []
     def row(label, key, pm=None, extra_frac=True):
         d = D[key]; r = d['roofline']; cb = d.get('cpu_baseline') or {}
-        cells = [label, '**%s** (%.2f)' % (rate(d['value']), r['kernel_avg_ms']) if pm else '%s (%.2f)' % (rate(d['value']), r['kernel_avg_ms']),
-                 '%s (%.2f)' % (rate(d['window']['value']), d['window']['kernel_avg_ms']),
+        cells = [label, '**%s** (%.2f)' % (rate(d['value']), kpc(r)) if pm else '%s (%.2f)' % (rate(d['value']), kpc(r)),
+                 '%s (%.2f)' % (rate(d['window']['value']), kpc(d['window'])),
                  '%.2f %% / %.2f %% (%.2f %%)' % (100 * r['frac'], 100 * r['frac_executed'], 100 * d['window']['frac']),
                  '%.2f' % r['list_rebuilds_per_sweep'], '%.0f %%' % (100 * PM[pm]['valu']) if pm else '', traffic_cell(pm) if pm else '',
                  '%s (%d thr) / %s' % (ks(cb['value']), cb['cores'], ks(cb['single_thread']['value'])) if cb else '',
@@ -93,12 +101,12 @@ def design_rows():
     row('C1 (2 x 2 x 256, Q = 8: 32 of 256 CUs)', 'C1')
     d = D['C2_iter']; cb = d['cpu_baseline']
     rows.append('| C2, iterative position moves (`--iterative`: cycles 3-7, window only) | — | %s (%.2f) | %.2f %% | %.2f | | | %s / %s | %.0fx | %s |'
-                % (rate(d['window']['value']), d['window']['kernel_avg_ms'], 100 * d['window']['frac'], d['window']['list_rebuilds_per_sweep'],
+                % (rate(d['window']['value']), kpc(d['window']), 100 * d['window']['frac'], d['window']['list_rebuilds_per_sweep'],
                    ks(cb['value']), ks(cb['single_thread']['value']), d['value'] / cb['value'], R3['C2_iter']))
     rows.append('| strong-scaling legs of the 8 x 8 grid: 32 / 16 / 8 replicas on one GPU (Q = 8) | %s / %s / %s (%.2f / %.2f / %.2f) | | | | | | | | 813 k / 416 k / 212 k |'
-                % (rate(D['C2_rows4']['value']), rate(D['C2_rows2']['value']), rate(D['C2_rows1']['value']), D['C2_rows4']['roofline']['kernel_avg_ms'],
-                   D['C2_rows2']['roofline']['kernel_avg_ms'], D['C2_rows1']['roofline']['kernel_avg_ms']))
-    head = ['| preset | sustained sweeps/s (kernel ms) | window (kernel ms) | fp64 frac, sustained: algorithmic / executed (window) | rebuilds per sweep | VALU issuing (PMC) | HBM-side traffic per launch / algorithmic | CPU all cores / one thread | x all-core CPU | round 3 sustained |',
+                % (rate(D['C2_rows4']['value']), rate(D['C2_rows2']['value']), rate(D['C2_rows1']['value']), kpc(D['C2_rows4']['roofline']),
+                   kpc(D['C2_rows2']['roofline']), kpc(D['C2_rows1']['roofline'])))
+    head = ['| preset | sustained sweeps/s (kernel ms per cycle) | window (kernel ms per cycle) | fp64 frac, sustained: algorithmic / executed (window) | rebuilds per sweep | VALU issuing (PMC) | HBM-side traffic per cycle / algorithmic | CPU all cores / one thread | x all-core CPU | round 3 sustained |',
             '|---|---|---|---|---|---|---|---|---|---|']
     return '\n'.join(head + rows)
 
@@ -121,7 +129,7 @@ def baseline_rows():
         return s
     r3 = {'C1': '109 614', 'C2': '1 394 520', 'C3': '352 236', 'C4': '713 500', 'C5': '214 180', 'runsh': '1 275 299'}
     def sp(c): return ('**%.0fx** (target >= 10x)' if c == 'C2' else '%.0fx') % (D[c]['value'] / D[c]['cpu_baseline']['value'])
-    def kms(c): return '%.2f' % D[c]['roofline']['kernel_avg_ms']
+    def kms(c): return '%.2f' % kpc(D[c]['roofline'])
     def fr(c):
         r = D[c]['roofline']
         if c == 'C1': return '%.2f %% (32 CUs)' % (100 * r['frac'])
@@ -138,8 +146,8 @@ def baseline_rows():
             '| CPU restatement, 1 core, sweeps/s | ' + cell(cpu1) + ' |', '| CPU restatement, all cores, sweeps/s | ' + cell(cpua) + ' |',
             '| MI355X sweeps/s, sustained (= `value`) | ' + cell(sus) + ' |', '| MI355X sweeps/s, window | ' + cell(win) + ' |',
             '| round 3, sustained | ' + cell(lambda c: r3[c]) + ' |', '| speed-up vs all-core CPU (sustained) | ' + cell(sp) + ' |',
-            '| kernel ms per launch, sustained | ' + cell(kms) + ' |', '| fp64 FLOP/s, algorithmic, sustained (fraction of 78.6 TF) | ' + cell(fr) + ' |',
-            '| algorithmic HBM GB/s (fraction of 8 TB/s); measured HBM-side traffic per launch (run.sh setting: 18x with full lists) | ' + cell(hb) + ' |',
+            '| kernel ms per cycle (one block of MOD moves per replica), sustained | ' + cell(kms) + ' |', '| fp64 FLOP/s, algorithmic, sustained (fraction of 78.6 TF) | ' + cell(fr) + ' |',
+            '| algorithmic HBM GB/s (fraction of 8 TB/s); measured HBM-side traffic per cycle (run.sh setting: 18x with full lists) | ' + cell(hb) + ' |',
             '| VALU issuing, share of SIMD cycles (PMC, equilibrated launches) | ' + cell(va) + ' |', '| list rebuilds per sweep, sustained | ' + cell(rb) + ' |']
     return '\n'.join(rows)
 

@@ -157,6 +157,10 @@ class OracleEngine:
 
     def set_step(self, step): self.step = int(step)
     def run_block(self, mod): self.loop.run_block(mod, self.step)
+
+    def run_cycles(self, ncycles, mod):
+        for k in range(ncycles):
+            self.loop.run_block(mod, self.step + k); self.loop.adapt(); self.loop.exchange(self.step + k)
     def thermo(self): return self.loop.rows()
     def adapt(self): self.loop.adapt()
 
@@ -207,6 +211,12 @@ class BenchOracleEngine(OracleEngine):
         self._ms += (self._time.perf_counter() - t0) * 1e3
         self._launches += 1
         self._blocks += 1
+
+    def run_cycles(self, ncycles, mod):
+        for k in range(ncycles):
+            self.run_block(mod); self.adapt(); self.exchange(count=False)
+            self.step += 1
+        self.step -= ncycles
 
     def constants(self): return self.loop.et.copy(), self.loop.pf.copy()
     def timing_reset(self): self._launches, self._ms = 0, 0.0

@@ -94,6 +94,39 @@ def test_driver_formats_with_oracle_engine(tmp_path, oracle):
         np.testing.assert_array_equal(pe, cols[1])
 
 
+def test_cycles_that_write_nothing_go_to_the_engine_as_one_call(tmp_path, oracle):
+    """-sc 5 of 8 cycles with a restart dump every 3: cycles 0-1 and 3-4 neither record nor dump and go out as run_cycles(2) each; the
+    dump cycles (2, 5), the recorded ones (5, 6, 7) and the last go the single way — and every file equals the one of a driver whose engine
+    has no run_cycles at all"""
+    argv = '-bm -e LJ -ss 4 -pn 2 -tn 2 -sn 8 -sm 3 -sc 5 -rd 3'.split()
+    calls = []
+
+    class Counting(OracleEngine):
+        def run_cycles(self, ncycles, mod):
+            calls.append((self.step, ncycles))
+            OracleEngine.run_cycles(self, ncycles, mod)
+
+    class Plain(OracleEngine):
+        run_cycles = property()     # hasattr() is False: the driver takes the cycle-by-cycle path
+
+    a = tmp_path / 'a'; b = tmp_path / 'b'
+    a.mkdir(); b.mkdir()
+    ra = run_driver(a, argv + ['-n', 'q'], lambda r: Counting(oracle, r))
+    rb = run_driver(b, argv + ['-n', 'q'], lambda r: Plain(oracle, r))
+    assert calls == [(0, 2), (3, 2)]
+    check_outputs(a, ra, nrec=3)
+    for f in sorted(os.listdir(b)):
+        fa, fb = os.path.join(a, f), os.path.join(b, f)
+        if f.endswith('.npy'):
+            xa, xb = np.load(fa, allow_pickle=True), np.load(fb, allow_pickle=True)
+            if xa.dtype == object:
+                assert all(np.array_equal(np.asarray(u), np.asarray(w)) for ra_, rb_ in zip(xa, xb) for u, w in zip(ra_, rb_)), f
+            else:
+                assert np.array_equal(xa, xb), f
+        else:
+            assert open(fa, 'rb').read() == open(fb, 'rb').read(), f
+
+
 @pytest.mark.gpu
 def test_driver_end_to_end_gpu(tmp_path):
     argv = '-bm -n g1 -e LJ -ss 4 -pn 2 -tn 4 -sn 4 -sm 8 -sc 0 -rd 2'.split()
