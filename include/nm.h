@@ -119,10 +119,11 @@ int nm_run_block(nm_ctx *ctx, int mod);
 /* `ncycles` cycles of the main loop with outputs off (remcmc:977-995: gen_samples, gen_mc_params, replica_exchange; steps STEP .. STEP + ncycles - 1 of
    nm_set_step), asynchronous: the same chains, bit for bit, as ncycles times nm_run_block + nm_adapt + nm_exchange, queued by one call.  Needs whole
    pressure rows (NM_ERR_UNSUPPORTED otherwise).
-   NM_FUSED_CYCLES=1 in the environment makes it ONE launch (nm_cycles_kernel) where the grid runs as 4^3 clusters of 2 or 4 workgroups per replica: the
-   replicas of a pressure row meet after every block and rows never wait for one another (the exchange never leaves a row, remcmc:782-798).  Not the
-   default: what the rows gain (~3 % of a launch on the 8 x 8 grid) the block's code loses by being compiled inside the loop over cycles.
-   A hand-over that times out in the middle of such a launch leaves the rows at different cycles: reported as NM_ERR_STATE, not re-issued. */
+   Where the grid runs as 4^3 clusters of 2 or 4 workgroups per replica (64-128 replicas per GPU) it is ONE launch (nm_cycles_kernel): the replicas of a
+   pressure row meet after every block and rows never wait for one another (the exchange never leaves a row, remcmc:782-798) — +2.5 % on the 8 x 8 grid.
+   Elsewhere, and with tapes or a trace set, it is the loop of single launches (NM_FUSED_CYCLES=0 in the environment: always; =all: one launch wherever
+   the kernel exists).  A hand-over that times out in the middle of such a launch leaves the rows at different cycles: reported as NM_ERR_STATE, not
+   re-issued. */
 int nm_run_cycles(nm_ctx *ctx, int ncycles, int mod);
 /* rows[nslots][17] in the column order of remcmc:208 (values of the last nm_run_block; call before nm_adapt) */
 int nm_get_thermo(nm_ctx *ctx, double *rows);

@@ -239,17 +239,18 @@ hipError_t launch_cycles(const nm_ctx *c, const KParams &p)
     return hipGetLastError();
 }
 
-// nm_cycles_kernel is instantiated for the 4^3 clusters (LJ and Al) and the 6^3 cluster of eight.  nm_run_cycles uses it only when asked to
-// (NM_FUSED_CYCLES=1: the 4^3 clusters of 2 and 4; =all: every instantiation): measured on the 8 x 8 grid, rows that do not wait for one another are
-// worth ~3 % of a launch, and the block's code, compiled inside the loop over cycles, comes out ~3 % slower (three times the vector spills of
-// nm_block_kernel) — net -0.1 to +1.0 % at 2 and 4 workgroups per replica, -2 to -5 % at 8.  The default is the loop of single launches.
+// nm_cycles_kernel is instantiated for the 4^3 clusters (LJ and Al) and the 6^3 cluster of eight.  nm_run_cycles uses it where it measured faster
+// than the loop of single launches: the 4^3 clusters of 2 and 4 workgroups (64-128 replicas: +2.4 to +2.9 % LJ, +0.5 % Al).  Clusters of 8 run 32 replicas
+// or fewer, whose rows have little spread to hide, and there the block compiled inside the loop over cycles (~1 % slower) costs more than the rows gain
+// (-0.8 % at 4^3, -2.9 % at 6^3): the loop of single launches, unless NM_FUSED_CYCLES=all.  NM_FUSED_CYCLES=0: never.  DESIGN.md §7.4 (6).
 bool cycles_kind_built(const nm_ctx *c) { return (c->kind == 0 && c->cus >= 2) || (c->kind == 1 && c->cus == 8); }
 bool cycles_kind_ok(const nm_ctx *c)
 {
+    if (!cycles_kind_built(c)) return false;
     const char *e = std::getenv("NM_FUSED_CYCLES");
-    if (!e || !cycles_kind_built(c)) return false;
-    if (!std::strcmp(e, "all")) return true;
-    return !std::strcmp(e, "1") && c->kind == 0 && (c->cus == 2 || c->cus == 4);
+    if (e && !std::strcmp(e, "all")) return true;
+    if (e && !std::strcmp(e, "0")) return false;
+    return c->kind == 0 && (c->cus == 2 || c->cus == 4);
 }
 
 hipError_t launch_cycles_kind(const nm_ctx *c, const KParams &p)

@@ -2362,10 +2362,11 @@ enum : int { PH_INIT = 0, PH_BULK = 1, PH_VMC = 2, PH_HMC_START = 3, PH_HMC_STEP
 #endif
 // The block of one workgroup: returns 0 when the replica's block completed and was stored, 1 when this workgroup had nothing to run (halted
 // queue, padding workgroup, a slot the re-issue mask leaves out, nm_eval), 2 when the block stopped on an error (reported; state untouched).
-// `first`: the launch's residency census is taken (nm_cycles_kernel takes it in its first cycle only).
-template <class C>
-__device__ __forceinline__ int nm_block_body(const KParams &p, bool first)
+// CENSUS: the launch's residency census is taken here (nm_cycles_kernel takes it itself, once, in front of its cycles).
+template <class C, bool CENSUS = true>
+__device__ __forceinline__ int nm_block_body(const KParams &p)
 {
+    constexpr bool first = CENSUS;
     constexpr int BLOCK = C::BLOCK;
     const unsigned long long t_entry = wall_clock64(); // (stats column 4)
     // Cluster mapping: the Q members of a cluster share blockIdx % 8, i.e. one XCD (and its L2) under the observed round-robin
@@ -2679,7 +2680,7 @@ __device__ __forceinline__ int nm_block_body(const KParams &p, bool first)
 template <class C>
 __global__ void __launch_bounds__(C::BLOCK NM_MIN_WAVES) nm_block_kernel(const KParams p)
 {
-    (void)nm_block_body<C>(p, true);
+    (void)nm_block_body<C>(p);
 }
 
 // Launch order for grids with more one-workgroup replicas than the chip holds at once (the reference's run.sh setting: 1024 replicas
@@ -2774,16 +2775,23 @@ __device__ __forceinline__ int exchange_row(int r, int nt, int row0, uint32_t se
 template <class C>
 __global__ void __launch_bounds__(C::BLOCK NM_MIN_WAVES) nm_cycles_kernel(const KParams p0)
 {
-    const int ncycles = p0.ncycles, nt = p0.nt;
+    const int ncycles = p0.ncycles;
     const uint32_t step0 = p0.step, id0 = p0.launch_id;
-    const int Q = p0.cus, b = blockIdx.x;
-    const int r_ = b >> 3, qq = r_ % Q;
-    const int slot = (b & 7) + 8 * (r_ / Q); // (nm_block_body's mapping, without a launch-order table)
-    const int tid = threadIdx.x;
-    const bool real = slot < p0.nslots;
-    const int row = real ? slot / nt : 0;
-    const bool leader_wg = real && qq == 0 && slot == row * nt; // the workgroup that adapts and exchanges for its row
-    const unsigned int per_cycle = (unsigned int)(nt * Q); // workgroups of a row
+    {   // the launch's residency census, once, as nm_block_body takes it (halt word first; a slot's status cleared by its writer; nothing touched before it)
+        const int Q = p0.cus, b = blockIdx.x;
+        const int r_ = b >> 3, qq = r_ % Q;
+        const int slot = (b & 7) + 8 * (r_ / Q); // (nm_block_body's mapping, without a launch-order table)
+        const bool real = slot < p0.nslots, writer = threadIdx.x == 0 && qq == 0;
+        if (halted(p0)) return;
+        if (Q > 1 && p0.census) {
+            if (!real) { (void)residency_census<C>(p0, slot); return; } // padding workgroups take the census and leave
+            if (writer) p0.status[slot] = 0;
+            if (!residency_census<C>(p0, slot)) {
+                if (writer) report_status(p0, slot, ST_NOT_RESIDENT, true);
+                return;
+            }
+        } else if (!real) return;
+    }
 #pragma clang loop unroll(disable)
     for (int cyc = 0; cyc < ncycles; ++cyc) {
         // the parameters are fetched from the kernel's argument segment anew in every cycle: held across the loop they would occupy ~150 scalar registers
@@ -2795,10 +2803,17 @@ __global__ void __launch_bounds__(C::BLOCK NM_MIN_WAVES) nm_cycles_kernel(const 
         const KParams &p = pc;                       // (this cycle's copy)
         pc.step = step0 + (uint32_t)cyc;
         pc.launch_id = id0 + (uint32_t)cyc; // (distinguishes the hand-over granules of successive blocks)
-        int first = cyc == 0;                        // (opaque: the compiler would peel the first cycle off the loop, a second copy of the whole block)
-        asm volatile("" : "+v"(first));
-        const int rc = nm_block_body<C>(pc, __builtin_amdgcn_readfirstlane(first) != 0);
-        if (!real) return;                           // padding workgroups took part in the census and leave
+        const int rc = nm_block_body<C, false>(pc);
+        // the workgroup's place in the grid, worked out HERE from opaque copies of its indices: computed once in front of the loop, these values (and
+        // whatever the compiler derives from them for the code below) would be alive all the way through every block
+        int b = blockIdx.x, tid = threadIdx.x;
+        asm volatile("" : "+s"(b));
+        asm volatile("" : "+v"(tid));
+        const int nt = p.nt, Q = p.cus;
+        const int r_ = b >> 3, qq = r_ % Q;
+        const int slot = (b & 7) + 8 * (r_ / Q), row = slot / nt;
+        const bool leader_wg = qq == 0 && slot == row * nt; // the workgroup that adapts and exchanges for its row
+        const unsigned int per_cycle = (unsigned int)(nt * Q); // workgroups of a row
         if (rc != 0) {                               // stopped (or nothing to run): the rows must not wait for this workgroup
             if (tid == 0) __hip_atomic_store(p.cyc_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;

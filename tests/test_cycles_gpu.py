@@ -33,8 +33,8 @@ def _everything(e):
 
 
 # (element, sz, pressure rows, temperatures, workgroups per replica the grid gets, has a fused kernel?)
-# The fused kernel is instantiated for 4^3 at 2, 4, 8 workgroups per replica and 6^3 at 8; nm_run_cycles uses it when NM_FUSED_CYCLES says so
-# (1: 4^3 at 2 and 4; all: every instantiation — what the comparison below sets).  Without it nm_run_cycles is the loop of single launches.
+# The fused kernel is instantiated for 4^3 at 2, 4, 8 workgroups per replica and 6^3 at 8; nm_run_cycles uses it where it measured faster (4^3 at 2
+# and 4), everywhere under NM_FUSED_CYCLES=all — what the comparison below sets, so that every instantiation is checked — and nowhere under =0.
 CASES = [('LJ', 4, 4, 8, 8, True), ('LJ', 4, 8, 8, 4, True), ('LJ', 4, 16, 8, 2, True), ('LJ', 4, 32, 8, 1, False),
          ('LJ', 4, 2, 16, 8, True), ('LJ', 4, 3, 5, 8, True),
          ('Al', 4, 8, 8, 4, True), ('Al', 4, 16, 8, 2, True),
@@ -78,11 +78,11 @@ def test_fused_cycles_equal_the_loop_of_single_calls(monkeypatch, el, sz, npn, n
 
 
 def test_which_grids_run_their_cycles_as_one_launch():
-    """the default is the loop of single launches; NM_FUSED_CYCLES=1 makes one launch of the 4^3 clusters of 2 and 4 workgroups, =all of every
-    configuration that has the kernel"""
+    """one launch for the 4^3 clusters of 2 and 4 workgroups by default, for every configuration that has the kernel under NM_FUSED_CYCLES=all,
+    the loop of single launches under =0 and wherever there is no such kernel"""
     import neuralmelting_amd as nm
     import os
-    for env, ones in ((None, ()), ('1', (4, 2)), ('all', (4, 2, 8))):
+    for env, ones in ((None, (4, 2)), ('0', ()), ('all', (4, 2, 8))):
         for npn, ntn, cus in ((8, 8, 4), (16, 8, 2), (4, 8, 8), (32, 8, 1)):
             if env is None:
                 os.environ.pop('NM_FUSED_CYCLES', None)
@@ -158,7 +158,6 @@ def test_a_fused_launch_that_is_not_resident_is_reissued_whole(monkeypatch):
     x, v, box, d = lattice.init_states(4, P, T, 0.03125, 0.03125)
     ncyc, mod = 4, 12
     monkeypatch.setenv('NM_INJECT_CENSUS', '0')
-    monkeypatch.setenv('NM_FUSED_CYCLES', '1')
     a = nm.Engine(256, P, T)
     assert a.cus_per_replica == 4
     a.set_state(x, v, box, d)
