@@ -119,7 +119,7 @@ int nm_run_block(nm_ctx *ctx, int mod);
 /* `ncycles` cycles of the main loop with outputs off (remcmc:977-995: gen_samples, gen_mc_params, replica_exchange; steps STEP .. STEP + ncycles - 1 of
    nm_set_step), asynchronous: the same chains, bit for bit, as ncycles times nm_run_block + nm_adapt + nm_exchange, queued by one call.  Needs whole
    pressure rows (NM_ERR_UNSUPPORTED otherwise).
-   Where the grid runs as 4^3 clusters of 2 or 4 workgroups per replica (64-128 replicas per GPU) it is ONE launch (nm_cycles_kernel): the replicas of a
+   Where the grid runs as 4^3 clusters of 2 or 4 workgroups per replica (64-128 replicas per GPU) it is ONE launch per 64 cycles (nm_cycles_kernel): the replicas of a
    pressure row meet after every block and rows never wait for one another (the exchange never leaves a row, remcmc:782-798) — +2.5 % on the 8 x 8 grid.
    Elsewhere, and with tapes or a trace set, it is the loop of single launches (NM_FUSED_CYCLES=0 in the environment: always; =all: one launch wherever
    the kernel exists).  A hand-over that times out in the middle of such a launch leaves the rows at different cycles: reported as NM_ERR_STATE, not

@@ -419,6 +419,15 @@ int issue_cycles(nm_ctx *c, int ncycles, int mod, uint32_t step, bool timed)
         }
         return NM_OK;
     }
+    // a launch holds at most 64 cycles (what the rows gain by not waiting is there after ~10; a kernel that runs for minutes serves nobody)
+    constexpr int MAX_PER_LAUNCH = 64;
+    if (ncycles > MAX_PER_LAUNCH) {
+        for (int k = 0; k < ncycles; k += MAX_PER_LAUNCH) {
+            const int rc = issue_cycles(c, std::min(MAX_PER_LAUNCH, ncycles - k), mod, step + (uint32_t)k, timed);
+            if (rc) return rc;
+        }
+        return NM_OK;
+    }
     const int nrows = c->cfg.nrows;
     if (!c->d_rowsync) HIPCHK(c, dalloc(&c->d_rowsync, (size_t)2 * nrows + 2));
     HIPCHK(c, hipMemsetAsync(c->d_rowsync, 0, sizeof(unsigned int) * ((size_t)2 * nrows + 2), c->stream));

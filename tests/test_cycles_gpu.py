@@ -102,6 +102,28 @@ def test_which_grids_run_their_cycles_as_one_launch():
                 os.environ.pop('NM_FUSED_CYCLES', None)
 
 
+def test_a_long_call_is_cut_into_launches_of_at_most_64_cycles():
+    import neuralmelting_amd as nm
+    from neuralmelting_amd import lattice
+    P, T = grids(8, 8)
+    x, v, box, d = lattice.init_states(4, P, T, 0.03125, 0.03125)
+    a = nm.Engine(256, P, T)
+    a.set_state(x, v, box, d)
+    a.timing_reset()
+    a.set_step(0)
+    a.run_cycles(150, 1)
+    got = _everything(a)
+    assert a.timing()[0] == 3                                        # 64 + 64 + 22
+    a.close()
+    b = nm.Engine(256, P, T)
+    b.set_state(x, v, box, d)
+    _single(b, 0, 150, 1)
+    want = _everything(b)
+    b.close()
+    for key in want:
+        np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+
+
 def test_fused_cycles_against_the_oracles_main_loop(oracle, monkeypatch):
     """the oracle's gen_samples / gen_mc_params / replica_exchange, four cycles, against one fused launch"""
     monkeypatch.setenv('NM_FUSED_CYCLES', 'all')
