@@ -1,5 +1,8 @@
+"""nm_run_cycles against the loop of nm_run_block + nm_adapt + nm_exchange on the 8 x 8 C2 grid: wall time of each and whether thermo rows, positions,
+velocities and the slot permutation are equal bit for bit (the quick check used while nm_cycles_kernel was built; the tests proper are
+tests/test_cycles_gpu.py).  NM_FUSED_CYCLES=0 / all select the launch shape."""
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import neuralmelting_amd as nm
 from neuralmelting_amd import lattice
