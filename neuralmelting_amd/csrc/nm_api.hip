@@ -612,6 +612,10 @@ int settle(nm_ctx *c)
         }
         // ---- not curable here: report once, leave the context usable
         c->journal.clear();
+        // launches queued behind the one that stopped found the halt word armed and left BEFORE their residency census, while the host had already
+        // advanced the census base for them: start the counters afresh, or the next launch's census comes up short and is taken for a grid that
+        // is not resident (re-issued at fewer workgroups per replica for no reason)
+        if (halt) HIPCHK(c, reset_census(c));
         HIPCHK(c, hipMemcpy(c->d_status, st.data(), sizeof(int) * c->nslots, hipMemcpyHostToDevice)); // nm_get_status: what stopped which slot
         HIPCHK(c, hipMemset(c->d_status_acc, 0, sizeof(int) * c->nslots));
         HIPCHK(c, hipMemset(c->d_halt, 0, sizeof(int)));

@@ -202,3 +202,50 @@ def test_a_fused_launch_that_is_not_resident_is_reissued_whole(monkeypatch):
     b.close()
     for key in want:
         np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+
+
+def test_an_error_inside_a_fused_launch_is_loud_and_the_grid_drains(monkeypatch):
+    """A replica that stops on an error in the middle of a fused launch (an injected list overflow) sets the launch's abort word: the other workgroups
+    of its row do not sit out the 2 s of a hand-over timeout, the other rows leave at their next barrier, the host gets NM_ERR_STATE once with the slot
+    and the reason — and the context is usable again from a state the caller sets."""
+    import time
+    import neuralmelting_amd as nm
+    from neuralmelting_amd import _lib as B
+    from neuralmelting_amd import lattice
+    P, T = grids(8, 8)
+    x, v, box, d = lattice.init_states(4, P, T, 0.03125, 0.03125)
+    e = nm.Engine(256, P, T)
+    e.set_state(x, v, box, d)
+    e.run_block(8)
+    e.synchronize()
+    monkeypatch.setenv('NM_INJECT_OVERFLOW', '3,1')
+    e.timing_reset()
+    e.set_step(1)
+    t0 = time.perf_counter()
+    e.run_cycles(6, 48)
+    e.set_step(7)
+    e.run_block(48)
+    with pytest.raises(nm.NMError) as ei:
+        e.synchronize()
+    assert time.perf_counter() - t0 < 1.0                             # six cycles are ~35 ms; a timeout would be 2 s
+    monkeypatch.delenv('NM_INJECT_OVERFLOW')
+    assert ei.value.code == B.NM_ERR_STATE and 'neighbour list overflow' in str(ei.value)
+    st = e.status()
+    assert (st != 0).any() and (st[st != 0] == 1).all()               # NM_ST_LIST_OVERFLOW and nothing else: nobody timed out waiting
+    # usable again: the same three cycles as a fresh context
+    e.adapt()                                                         # (zero the counters and ratios the stopped launch left ...
+    e.set_state(x, v, box, d)                                         #  ... then the state, step sizes included)
+    e.set_step(0)
+    e.run_cycles(3, 8)
+    got = _everything(e)
+    cus_after, heals_after = e.lib.nm_cus_per_replica(e.h), e.heals
+    e.close()
+    f = nm.Engine(256, P, T)
+    f.set_state(x, v, box, d)
+    f.set_step(0)
+    f.run_cycles(3, 8)
+    want = _everything(f)
+    f.close()
+    assert (got['status'] == 0).all() and cus_after == 4 and heals_after == 0   # (the launches behind the error left the census counters in step)
+    for key in ('x', 'v', 'box', 'd'):                                 # (not the slot-to-buffer map: rows that got ahead of the error had exchanged)
+        np.testing.assert_array_equal(got[key], want[key], err_msg=key)

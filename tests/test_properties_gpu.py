@@ -237,6 +237,12 @@ def test_nothing_runs_behind_a_block_that_stopped(monkeypatch):
     x3 = f.get_state()[0]
     f.close()
     np.testing.assert_array_equal(x2[~stopped], x3[~stopped])
+    # the launches queued behind the failed block left before their residency census: the next launch must not mistake the short count for a grid
+    # that is not resident (it would be re-issued at fewer workgroups per replica)
+    e.set_step(4)
+    e.run_block(8)
+    e.synchronize()
+    assert (e.status() == 0).all() and e.lib.nm_cus_per_replica(e.h) == 4 and e.heals == 0 and e.note() == ''
     e.close()
 
 
