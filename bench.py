@@ -372,7 +372,8 @@ def run_leg(args, env, scaling, with_cpu):
             'roofline': {'bound': 'fp64-valu', 'achieved': sus['achieved'], 'peak': FP64_VEC_PEAK_TF, 'unit': 'TFLOP/s',
                          'frac': sus['frac'], 'traffic': prof.get('traffic'), 'traffic_range': prof.get('traffic_range'),
                          'kernel': 'nm_cycles_kernel' if sus['cycles_per_launch'] > 1 else 'nm_block_kernel', 'kernel_avg_ms': sus['kernel_avg_ms'],
-                         'launches': sus['launches'], 'cycles_per_launch': sus['cycles_per_launch'],
+                         'launches': sus['launches'], 'cycles_per_launch': sus['cycles_per_launch'],   # a timed region is ONE launch of nm_cycles_kernel where nm_run_cycles fuses it
+                         'kernel_ms_per_cycle': sus['kernel_avg_ms'] / sus['cycles_per_launch'],
                          'launches_that_did_no_work': heals_s,   # blocks re-issued at fewer workgroups per replica inside the region (not in kernel_avg_ms)
                          'algorithmic_flop_per_launch': sus['algorithmic_flop_per_launch'], 'algorithmic_evals_per_sweep': evals_alg,
                          'executed': sus['executed'], 'frac_executed': sus['frac_executed'], 'evals_per_sweep': sus['evals_per_sweep'],
