@@ -141,6 +141,24 @@ def test_driver_end_to_end_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_driver_with_a_sample_cutoff_writes_the_same_files_fused_or_not(tmp_path, monkeypatch):
+    """-sc 8 of 12 cycles on the 8 x 8 grid, restart dump every 5: the cycles in front of the cutoff that neither record nor dump go to the engine as
+    run_cycles (one launch each on this grid); every file the run leaves equals, byte for byte, the one of a run whose engine makes single launches of them"""
+    argv = '-bm -e LJ -ss 4 -pn 8 -tn 8 -sn 12 -sm 8 -sc 8 -rd 5'.split()
+    a = tmp_path / 'a'; b = tmp_path / 'b'
+    a.mkdir(); b.mkdir()
+    ra = run_driver(a, argv + ['-n', 'q'])
+    monkeypatch.setenv('NM_FUSED_CYCLES', '0')
+    run_driver(b, argv + ['-n', 'q'])
+    monkeypatch.delenv('NM_FUSED_CYCLES')
+    check_outputs(a, ra, nrec=4)
+    names = sorted(os.listdir(b))
+    assert names == sorted(os.listdir(a)) and any(n.endswith('.thrm') for n in names)
+    for f in names:
+        assert open(os.path.join(a, f), 'rb').read() == open(os.path.join(b, f), 'rb').read(), f
+
+
+@pytest.mark.gpu
 def test_pipeline_sampler_parse_distr_gpu(tmp_path, monkeypatch):
     """run.sh's first three stages (run.sh:7-16) on the build's own modules: sampler -> parse -> distr, file to file"""
     from neuralmelting_amd import distr, parse
